@@ -1,0 +1,14 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+if ROOT not in sys.path:
+	sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+	config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')

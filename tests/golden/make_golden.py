@@ -1,0 +1,352 @@
+#!/usr/bin/env python
+"""Generate the golden vectors under tests/golden/ by RUNNING THE REFERENCE.
+
+Run in the build container only (needs /root/reference):
+
+    python tests/golden/make_golden.py
+
+The reference (pure Python, v4.7.1) is imported through ``ref_harness`` and
+executed on
+  * the known-answer inputs of its own unit tests (tests/bayesdistance_test.py:12-32,
+    tests/fastskymatch_test.py:16-29),
+  * its shipped fixtures tests/elltest/randomcat{X,R,O}.fits (2-way and 3-way),
+  * its shipped doc/COSMOS_XMM.fits against seeded uniform stand-ins for the two
+    catalogues that are missing from the checkout (.MISSING_LARGE_BLOBS),
+  * small adversarial tables (negative declination cells, lone primaries, ties).
+Outputs are .npz files holding INPUTS and EXPECTED OUTPUTS only (data, no code).
+"""
+import os
+import sys
+import warnings
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+from ref_harness import load_reference, REFERENCE  # noqa: E402
+from nway_amd import _fits  # noqa: E402
+
+warnings.simplefilter('ignore')
+ref = load_reference()
+LOG = ref.NullOutputLogger()
+raw_crossproduct = ref.match.crossproduct.func
+
+FLOATCOLS = ['Separation_max', 'dist_bayesfactor_uncorrected', 'dist_bayesfactor', 'dist_post',
+	'p_single', 'prob_has_match', 'prob_this_match']
+
+
+def save(name, **arrays):
+	path = os.path.join(HERE, name + '.npz')
+	np.savez_compressed(path, **arrays)
+	print('%-14s %8.1f KB  %s' % (name, os.path.getsize(path) / 1024., ' '.join(sorted(arrays))[:100]))
+
+
+def microdeg(x):
+	"""store 6-decimal coordinates exactly as integers (x == i / 1e6 bit for bit)"""
+	i = np.round(np.asarray(x, dtype=float) * 1e6).astype(np.int64)
+	assert (i / 1e6 == x).all()
+	return i
+
+
+def cat(name, ra, dec, error, area):
+	return dict(name=name, ra=np.array(ra, dtype=float), dec=np.array(dec, dtype=float),
+		error=np.array(error, dtype=float), area=area, mags=[], maghists=[], magnames=[])
+
+
+def run(tables, radius, completeness, **kw):
+	tables = [dict(t, ra=t['ra'].copy(), dec=t['dec'].copy(), error=t['error'].copy()) for t in tables]
+	return ref.nway_match(tables, match_radius=radius, prior_completeness=completeness, logger=LOG, **kw)
+
+
+def table_arrays(res, names, prefix=''):
+	out = {}
+	k = len(names)
+	out[prefix + 'idx'] = np.stack([res[n].values for n in names], axis=1).astype(np.int32)
+	for i in range(k):
+		for j in range(i + 1, k):
+			out[prefix + 'sep_%d_%d' % (i, j)] = res['Separation_%s_%s' % (names[i], names[j])].values
+	for c in FLOATCOLS:
+		out[prefix + c] = res[c].values
+	out[prefix + 'ncat'] = res['ncat'].values.astype(np.int8)
+	out[prefix + 'match_flag'] = res['match_flag'].values.astype(np.int8)
+	return out
+
+
+def checksums(res, names, prefix=''):
+	"""order-sensitive integer checksum of the index table + float column sums"""
+	out = {}
+	idx = np.stack([res[n].values for n in names], axis=1).astype(np.int64)
+	w = np.arange(1, len(idx) + 1, dtype=np.uint64)
+	h = np.uint64(0)
+	for c in range(idx.shape[1]):
+		h = h + ((idx[:, c] + 2).astype(np.uint64) * np.uint64(1000003 + 7919 * c) * w).sum(dtype=np.uint64)
+	out[prefix + 'idx_hash'] = np.array([h], dtype=np.uint64)
+	out[prefix + 'nrows'] = np.array([len(idx)])
+	out[prefix + 'rows_per_primary'] = np.bincount(idx[:, 0]).astype(np.int32)
+	for c in FLOATCOLS:
+		out[prefix + 'sum_' + c] = np.array([res[c].values.sum()])
+	k = len(names)
+	for i in range(k):
+		for j in range(i + 1, k):
+			out[prefix + 'sum_sep_%d_%d' % (i, j)] = np.array([np.nansum(res['Separation_%s_%s' % (names[i], names[j])].values)])
+	out[prefix + 'flag_counts'] = np.bincount(res['match_flag'].values, minlength=3)
+	out[prefix + 'ncat_counts'] = np.bincount(res['ncat'].values, minlength=k + 1)
+	return out
+
+
+def subset_rows(res, names, step, prefix=''):
+	"""full rows of every ``step``-th primary"""
+	prim = res[names[0]].values
+	mask = (prim % step) == 0
+	sub = res[mask]
+	out = table_arrays(sub, names, prefix + 'sub_')
+	out[prefix + 'sub_step'] = np.array([step])
+	out[prefix + 'sub_rows'] = np.flatnonzero(mask).astype(np.int64)
+	return out
+
+
+# ---------------------------------------------------------------------------
+def gen_kat_math():
+	bd = ref.bayesdist
+	sep = np.array([0., 0.1, 0.2, 0.3, 0.4, 0.5])
+	out = dict(sep=sep)
+	out['log_bf2'] = np.array([bd.log_bf2(p, 0.1, 0.2) for p in sep])
+	out['log_bf_n2'] = np.array([bd.log_bf([[None, p]], [0.1, 0.2]) for p in sep])
+	out['log_bf3'] = np.array([bd.log_bf3(p, p, p, 0.1, 0.2, 0.3) for p in sep])
+	out['log_bf_n3'] = np.array([bd.log_bf([[None, p, p], [p, None, p], [p, p, None]], [0.1, 0.2, 0.3]) for p in sep])
+	out['log_bf_n1'] = np.atleast_1d(bd.log_bf([[None]], [0.5]))
+	out['log_arcsec2rad'] = np.array([bd.log_arcsec2rad])
+	# vectorised 4-way call with distinct separations/sigmas
+	rng = np.random.RandomState(7)
+	n = 257
+	s4 = [rng.uniform(0.05, 3, size=n) for _ in range(4)]
+	p4 = [[rng.uniform(0, 5, size=n) if i < j else np.nan * np.ones(n) for j in range(4)] for i in range(4)]
+	out['n4_sigma'] = np.array(s4)
+	out['n4_sep'] = np.array([[p4[i][j] for j in range(4)] for i in range(4)])
+	out['n4_log_bf'] = bd.log_bf(p4, s4)
+	prior = 10**rng.uniform(-12, -0.01, size=n)
+	lbf = rng.uniform(-30, 30, size=n)
+	out['post_prior'] = prior
+	out['post_logbf'] = lbf
+	out['posterior'] = bd.posterior(prior, lbf)
+	out['log_posterior'] = bd.log_posterior(prior, lbf)
+	out['unnormalised_log_posterior'] = bd.unnormalised_log_posterior(prior, lbf, 2)
+	out['posterior_scalar'] = np.array([bd.posterior(1e-3, 2.5), bd.log_posterior(1e-3, 2.5)])
+	# dist: inputs of tests/fastskymatch_test.py:16-29
+	out['dist_scalar'] = np.array([ref.match.dist((53.15964508, -27.92927742), (53.15953445, -27.9313736))])
+	ra = np.array([53.14784241, 53.14784241, 53.14749908, 53.16559982, 53.19423676, 53.1336441])
+	dec = np.array([-27.79363823, -27.79363823, -27.81790352, -27.79622459, -27.70860672, -27.76327515])
+	ra2 = np.array([53.14907837, 53.14907837, 53.1498642, 53.16150284, 53.19681549, 53.13626862])
+	dec2 = np.array([-27.79297447, -27.79297447, -27.81404877, -27.79223251, -27.71365929, -27.76314735])
+	out['dist_ra'], out['dist_dec'], out['dist_ra2'], out['dist_dec2'] = ra, dec, ra2, dec2
+	out['dist_array'] = ref.match.dist((ra, dec), (ra2, dec2))
+	# dist over the whole sphere incl. poles, antipodes, identical points, RA wrap
+	n = 4096
+	a_ra = rng.uniform(0, 360, size=n)
+	a_dec = np.degrees(np.arcsin(rng.uniform(-1, 1, size=n)))
+	b_ra = a_ra + rng.normal(0, 1, size=n) * 10**rng.uniform(-7, 2, size=n)
+	b_dec = np.clip(a_dec + rng.normal(0, 1, size=n) * 10**rng.uniform(-7, 2, size=n), -90, 90)
+	a_dec[:4] = [90, -90, 0, 45]
+	b_dec[:4] = [-90, -90, 0, 45]
+	b_ra[2:4] = a_ra[2:4]
+	b_ra[4] = a_ra[4] + 360
+	out['sph_a_ra'], out['sph_a_dec'], out['sph_b_ra'], out['sph_b_dec'] = a_ra, a_dec, b_ra, b_dec
+	out['sph_dist'] = ref.match.dist((a_ra, a_dec), (b_ra, b_dec))
+	save('kat_math', **out)
+
+
+def load_elltest():
+	X = _fits.read_table(os.path.join(REFERENCE, 'tests/elltest/randomcatX.fits'))
+	R = _fits.read_table(os.path.join(REFERENCE, 'tests/elltest/randomcatR.fits'))
+	O = _fits.read_table(os.path.join(REFERENCE, 'tests/elltest/randomcatO.fits'))
+	return X, R, O
+
+
+def gen_ell():
+	X, R, O = load_elltest()
+	inputs = dict(
+		X_ra_u=microdeg(X.data['RA']), X_dec_u=microdeg(X.data['DEC']), X_err_u=microdeg(X.data['pos_err']),
+		R_ra_u=microdeg(R.data['RA']), R_dec_u=microdeg(R.data['DEC']), R_err_u=microdeg(R.data['pos_err']),
+		O_ra_u=microdeg(O.data['RA']).astype(np.int32), O_dec_u=microdeg(O.data['DEC']).astype(np.int32),
+		area=np.array([X.header['SKYAREA'], R.header['SKYAREA'], O.header['SKYAREA']]),
+		names=np.array([X.name, R.name, O.name]),
+	)
+	save('ell_inputs', **inputs)
+	tX = cat(X.name, X.data['RA'], X.data['DEC'], X.data['pos_err'], X.header['SKYAREA'])
+	tR = cat(R.name, R.data['RA'], R.data['DEC'], R.data['pos_err'], R.header['SKYAREA'])
+	tO = cat(O.name, O.data['RA'], O.data['DEC'], 0.1 * np.ones(len(O.data)), O.header['SKYAREA'])
+	# --- 2-way
+	cp = raw_crossproduct([(tX['ra'], tX['dec']), (tO['ra'], tO['dec'])], 10. / 60 / 60, LOG)
+	out = dict(crossproduct=cp.astype(np.int32), radius=np.array([10.]))
+	res = run([tX, tO], 10., 1.0)
+	names = [X.name, O.name]
+	out.update(table_arrays(res, names, 'c10_'))
+	out.update(checksums(res, names, 'c10_'))
+	res9 = run([tX, tO], 10., 0.9)
+	out.update(checksums(res9, names, 'c09_'))
+	f1 = res9['match_flag'].values == 1
+	out.update(dict(('c09_best_' + c, res9[c].values[f1]) for c in FLOATCOLS))
+	out['c09_match_flag'] = res9['match_flag'].values.astype(np.int8)
+	resm = run([tX, tO], 10., 0.9, min_prob=0.01, prob_ratio_secondary=0.25)
+	out.update(table_arrays(resm, names, 'trunc_'))
+	save('ell2', **out)
+	# --- 3-way
+	cp3 = raw_crossproduct([(tX['ra'], tX['dec']), (tR['ra'], tR['dec']), (tO['ra'], tO['dec'])], 10. / 60 / 60, LOG)
+	names3 = [X.name, R.name, O.name]
+	w = np.arange(1, len(cp3) + 1, dtype=np.uint64)
+	h = np.uint64(0)
+	for c in range(3):
+		h = h + ((cp3[:, c] + 2).astype(np.uint64) * np.uint64(1000003 + 7919 * c) * w).sum(dtype=np.uint64)
+	out = dict(crossproduct_nrows=np.array([len(cp3)]), crossproduct_hash=np.array([h], dtype=np.uint64),
+		crossproduct_rows_per_primary=np.bincount(cp3[:, 0]).astype(np.int32), radius=np.array([10.]))
+	res3 = run([tX, tR, tO], 10., 1.0)
+	out.update(checksums(res3, names3, 'c10_'))
+	out.update(subset_rows(res3, names3, 13, 'c10_'))
+	# CLI-behaviour correction (nway.py:366-420), evaluated by a literal transcription
+	# of that loop on the reference's own intermediate arrays
+	out.update(cli_correction(ref, [tX, tR, tO], 10., 1.0))
+	save('ell3', **out)
+
+
+def cli_correction(ref, tables, radius, completeness):
+	"""nway.py:366-420 transcribed; consumes the reference's own separations/errors/log_bf."""
+	tables = [dict(t, ra=t['ra'].copy(), dec=t['dec'].copy(), error=t['error'].copy()) for t in tables]
+	table, resultstable, separations, errors = ref._create_match_table(tables, radius, logger=LOG)
+	dens, dens_plus = ref._compute_source_densities(tables, logger=LOG)
+	prior, log_bf = ref._compute_single_log_bf(tables, dens, dens_plus, table, separations, errors, completeness, logger=LOG)
+	bd = ref.bayesdist
+	ncat = table['ncat'].values
+	ncats = len(tables)
+	prim = resultstable[:, 0]
+	starts = np.flatnonzero(np.r_[True, prim[1:] != prim[:-1]])
+	ends = np.r_[starts[1:], len(prim)]
+	group_of = np.repeat(np.arange(len(starts)), ends - starts)
+	corrected = log_bf.copy()
+	for i in np.where(ncat <= ncats - 2)[0]:
+		missing_cats = [k for k, sep in enumerate(separations[0]) if np.isnan(sep[i])]
+		best_logpost = 0
+		g = group_of[i]
+		for j in range(starts[g], ends[g]):
+			if not (ncat[j] > 2):
+				continue
+			augmented_cats = [k for k in missing_cats if not np.isnan(separations[0][k][j])]
+			if len(augmented_cats) >= 2:
+				prior_j = dens[augmented_cats[0]] / np.prod(dens_plus[augmented_cats])
+				errors_selected = [[errors[k][j]] for k in augmented_cats]
+				separations_selected = [[[separations[k][k2][j]] for k2 in augmented_cats] for k in augmented_cats]
+				log_bf_j = bd.log_bf(np.array(separations_selected), np.array(errors_selected))
+				logpost_j = bd.unnormalised_log_posterior(prior_j, log_bf_j, len(augmented_cats))[0]
+				if logpost_j > best_logpost:
+					best_logpost = logpost_j
+		if best_logpost > 0:
+			corrected[i] += best_logpost
+	changed = np.flatnonzero(corrected != log_bf)
+	return dict(cli_changed_rows=changed, cli_correction=(corrected - log_bf)[changed],
+		cli_sum_correction=np.array([(corrected - log_bf).sum()]))
+
+
+def gen_xmm():
+	XMM = _fits.read_table(os.path.join(REFERENCE, 'doc/COSMOS_XMM.fits'))
+	d = XMM.data
+	inputs = dict(ID=d['ID'], RA=d['RA'], DEC=d['DEC'], pos_err=d['pos_err'], area=np.array([XMM.header['SKYAREA']]),
+		table_name=np.array([XMM.name]))
+	save('xmm_inputs', **inputs)
+	# seeded stand-ins for the missing COSMOS_OPTICAL / COSMOS_IRAC (same sizes as the real ones)
+	rng = np.random.RandomState(42)
+	n_opt, n_irac = 560536, 345512
+	opt_ra = rng.uniform(149.35, 150.87, size=n_opt)
+	opt_dec = rng.uniform(1.47, 2.96, size=n_opt)
+	irac_ra = rng.uniform(149.35, 150.87, size=n_irac)
+	irac_dec = rng.uniform(1.47, 2.96, size=n_irac)
+	tX = cat('XMM', d['RA'], d['DEC'], d['pos_err'].astype(float), 2.0)
+	tO = cat('OPT', opt_ra, opt_dec, 0.1 * np.ones(n_opt), 2.0)
+	tI = cat('IRAC', irac_ra, irac_dec, 0.5 * np.ones(n_irac), 2.0)
+	res = run([tX, tO], 20., 0.9)
+	names = ['XMM', 'OPT']
+	out = dict(seed=np.array([42]), n_opt=np.array([n_opt]), n_irac=np.array([n_irac]),
+		box=np.array([149.35, 150.87, 1.47, 2.96]), radius=np.array([20.]), completeness=np.array([0.9]))
+	out.update(table_arrays(res, names, 'w2_'))
+	out.update(checksums(res, names, 'w2_'))
+	res3 = run([tX, tO, tI], 20., 0.9)
+	names3 = ['XMM', 'OPT', 'IRAC']
+	out.update(checksums(res3, names3, 'w3_'))
+	out.update(subset_rows(res3, names3, 29, 'w3_'))
+	save('xmm_syn', **out)
+
+
+def gen_edge():
+	out = {}
+	# (1) cells straddling Dec = 0 (int() truncation toward zero), 3-way, with lone primaries
+	rng = np.random.RandomState(3)
+	n0, n1, n2 = 60, 900, 700
+	r = 30.
+	def box(n):
+		return rng.uniform(20.0, 20.12, size=n), rng.uniform(-0.06, 0.06, size=n)
+	a, b, c = box(n0), box(n1), box(n2)
+	a[0][:3] = [25., 26., 27.]  # three primaries far away from everything: groups of one row
+	t0 = cat('A', a[0], a[1], rng.uniform(1, 4, size=n0), 0.0144)
+	t1 = cat('B', b[0], b[1], rng.uniform(0.5, 2, size=n1), 0.0144)
+	t2 = cat('C', c[0], c[1], 1.0 * np.ones(n2), 0.0144)
+	cp = raw_crossproduct([(t0['ra'], t0['dec']), (t1['ra'], t1['dec']), (t2['ra'], t2['dec'])], r / 60 / 60, LOG)
+	res = run([t0, t1, t2], r, np.array([1.0, 0.8, 0.6]))
+	names = ['A', 'B', 'C']
+	for i, t in enumerate((t0, t1, t2)):
+		out['neg_ra%d' % i], out['neg_dec%d' % i], out['neg_err%d' % i] = t['ra'], t['dec'], t['error']
+	out['neg_area'] = np.array([0.0144])
+	out['neg_radius'] = np.array([r])
+	out['neg_completeness'] = np.array([1.0, 0.8, 0.6])
+	out['neg_crossproduct'] = cp.astype(np.int32)
+	out.update(table_arrays(res, names, 'neg_'))
+	out.update(cli_correction_prefixed(ref, [t0, t1, t2], r, np.array([1.0, 0.8, 0.6]), 'neg_'))
+	# (2) exact ties: two secondaries mirrored in RA about the primary (bit-equal separations are
+	#     not guaranteed; whatever the reference says is the expected answer) + a duplicate secondary
+	p_ra, p_dec = np.array([100.0, 100.5]), np.array([10.0, 10.0])
+	s_ra = np.array([100.0 + 1e-4, 100.0 - 1e-4, 100.5 + 2e-4, 100.5 + 2e-4, 100.5 - 3e-4])
+	s_dec = np.array([10.0, 10.0, 10.0, 10.0, 10.0 + 1e-4])
+	tp = cat('P', p_ra, p_dec, np.array([0.5, 0.7]), 1.0)
+	ts = cat('S', s_ra, s_dec, 0.2 * np.ones(5), 1.0)
+	res = run([tp, ts], 5., 0.95)
+	out['tie_p_ra'], out['tie_p_dec'], out['tie_p_err'] = tp['ra'], tp['dec'], tp['error']
+	out['tie_s_ra'], out['tie_s_dec'], out['tie_s_err'] = ts['ra'], ts['dec'], ts['error']
+	out['tie_radius'] = np.array([5.]); out['tie_completeness'] = np.array([0.95])
+	out.update(table_arrays(res, ['P', 'S'], 'tie_'))
+	# (3) a hopeless single candidate: p_i = 1 although log_bf is hugely negative
+	tp = cat('P', [50.0], [-30.0], [0.01], 1.0)
+	ts = cat('S', [50.0 + 1.2e-3], [-30.0], [0.01], 1.0)
+	res = run([tp, ts], 10., 0.9)
+	out['hop_p'] = np.array([50.0, -30.0, 0.01]); out['hop_s'] = np.array([50.0 + 1.2e-3, -30.0, 0.01])
+	out['hop_radius'] = np.array([10.]); out['hop_completeness'] = np.array([0.9])
+	out.update(table_arrays(res, ['P', 'S'], 'hop_'))
+	# (4) 4-way, small, for the generic k expansion
+	rng = np.random.RandomState(11)
+	tabs = []
+	for i, n in enumerate((25, 160, 140, 120)):
+		ra = rng.uniform(200.0, 200.05, size=n)
+		dec = rng.uniform(30.0, 30.05, size=n)
+		tabs.append(cat('T%d' % i, ra, dec, rng.uniform(0.5, 3., size=n), 0.0025))
+		out['k4_ra%d' % i], out['k4_dec%d' % i], out['k4_err%d' % i] = tabs[-1]['ra'], tabs[-1]['dec'], tabs[-1]['error']
+	cp = raw_crossproduct([(t['ra'], t['dec']) for t in tabs], 25. / 60 / 60, LOG)
+	res = run(tabs, 25., 0.7)
+	out['k4_area'] = np.array([0.0025]); out['k4_radius'] = np.array([25.]); out['k4_completeness'] = np.array([0.7])
+	out['k4_crossproduct_nrows'] = np.array([len(cp)])
+	out['k4_crossproduct_rows_per_primary'] = np.bincount(cp[:, 0], minlength=25).astype(np.int32)
+	out.update(table_arrays(res, ['T0', 'T1', 'T2', 'T3'], 'k4_'))
+	save('edge', **out)
+
+
+def cli_correction_prefixed(ref, tables, radius, completeness, prefix):
+	return dict((prefix + k, v) for k, v in cli_correction(ref, tables, radius, completeness).items())
+
+
+if __name__ == '__main__':
+	which = sys.argv[1:] or ['kat', 'ell', 'xmm', 'edge']
+	if 'kat' in which:
+		gen_kat_math()
+	if 'edge' in which:
+		gen_edge()
+	if 'ell' in which:
+		gen_ell()
+	if 'xmm' in which:
+		gen_xmm()

@@ -1,0 +1,101 @@
+"""helpers shared by the parity tests: golden-vector loading and table comparison"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+if ROOT not in sys.path:
+	sys.path.insert(0, ROOT)
+
+
+def golden(name):
+	return np.load(os.path.join(GOLDEN, name + '.npz'))
+
+
+def cat(name, ra, dec, error, area):
+	return dict(name=name, ra=np.array(ra, dtype=float), dec=np.array(dec, dtype=float),
+		error=np.array(error, dtype=float), area=float(area), mags=[], maghists=[], magnames=[])
+
+
+def ell_tables():
+	"""tests/elltest/randomcat{X,R,O}.fits of the reference, rebuilt exactly from the
+	micro-degree integers stored in ell_inputs.npz."""
+	g = golden('ell_inputs')
+	names = [str(n) for n in g['names']]
+	X = cat(names[0], g['X_ra_u'] / 1e6, g['X_dec_u'] / 1e6, g['X_err_u'] / 1e6, g['area'][0])
+	R = cat(names[1], g['R_ra_u'] / 1e6, g['R_dec_u'] / 1e6, g['R_err_u'] / 1e6, g['area'][1])
+	O = cat(names[2], g['O_ra_u'] / 1e6, g['O_dec_u'] / 1e6, 0.1 * np.ones(len(g['O_ra_u'])), g['area'][2])
+	return X, R, O
+
+
+def xmm_tables():
+	"""real COSMOS_XMM + the seeded uniform stand-ins for the missing OPT/IRAC catalogues
+	(same recipe as tests/golden/make_golden.py:gen_xmm)."""
+	g = golden('xmm_inputs')
+	s = golden('xmm_syn')
+	rng = np.random.RandomState(int(s['seed'][0]))
+	n_opt, n_irac = int(s['n_opt'][0]), int(s['n_irac'][0])
+	lo_ra, hi_ra, lo_dec, hi_dec = s['box']
+	opt_ra = rng.uniform(lo_ra, hi_ra, size=n_opt)
+	opt_dec = rng.uniform(lo_dec, hi_dec, size=n_opt)
+	irac_ra = rng.uniform(lo_ra, hi_ra, size=n_irac)
+	irac_dec = rng.uniform(lo_dec, hi_dec, size=n_irac)
+	X = cat('XMM', g['RA'], g['DEC'], g['pos_err'].astype(float), 2.0)
+	O = cat('OPT', opt_ra, opt_dec, 0.1 * np.ones(n_opt), 2.0)
+	I = cat('IRAC', irac_ra, irac_dec, 0.5 * np.ones(n_irac), 2.0)
+	return X, O, I
+
+
+def idx_hash(idx):
+	idx = np.asarray(idx).astype(np.int64)
+	w = np.arange(1, len(idx) + 1, dtype=np.uint64)
+	h = np.uint64(0)
+	for c in range(idx.shape[1]):
+		h = h + ((idx[:, c] + 2).astype(np.uint64) * np.uint64(1000003 + 7919 * c) * w).sum(dtype=np.uint64)
+	return h
+
+
+FLOATCOLS = ['Separation_max', 'dist_bayesfactor_uncorrected', 'dist_bayesfactor', 'dist_post',
+	'p_single', 'prob_has_match', 'prob_this_match']
+
+# Tolerances of the parity contract (BASELINE.json north_star: 1e-6 relative on floating
+# columns, match_flag/index columns bit-identical).  The absolute term covers columns that
+# are differences of O(1) numbers (p_any = 1 - 10**x) or exactly-zero separations, where a
+# relative error is undefined at the 1e-16 rounding level of either implementation.
+RTOL = 1e-6
+ATOL = 1e-12
+
+
+def assert_table_matches(table, g, prefix, names, rows=None, rtol=RTOL, atol=ATOL):
+	"""compare a result table (dict of arrays) with golden arrays stored under ``prefix``"""
+	k = len(names)
+	sel = (lambda a: a) if rows is None else (lambda a: np.asarray(a)[rows])
+	idx = np.stack([sel(table[n]) for n in names], axis=1)
+	np.testing.assert_array_equal(idx, g[prefix + 'idx'])
+	np.testing.assert_array_equal(sel(table['ncat']), g[prefix + 'ncat'])
+	np.testing.assert_array_equal(sel(table['match_flag']), g[prefix + 'match_flag'])
+	for i in range(k):
+		for j in range(i + 1, k):
+			np.testing.assert_allclose(sel(table['Separation_%s_%s' % (names[i], names[j])]),
+				g[prefix + 'sep_%d_%d' % (i, j)], rtol=rtol, atol=1e-9, equal_nan=True)
+	for c in FLOATCOLS:
+		np.testing.assert_allclose(sel(table[c]), g[prefix + c], rtol=rtol, atol=atol, err_msg=c)
+
+
+def assert_checksums_match(table, g, prefix, names, rtol=1e-9):
+	k = len(names)
+	idx = np.stack([table[n] for n in names], axis=1)
+	assert len(idx) == int(g[prefix + 'nrows'][0])
+	np.testing.assert_array_equal(np.bincount(idx[:, 0], minlength=len(g[prefix + 'rows_per_primary'])),
+		g[prefix + 'rows_per_primary'])
+	assert idx_hash(idx) == g[prefix + 'idx_hash'][0]
+	np.testing.assert_array_equal(np.bincount(table['match_flag'], minlength=3), g[prefix + 'flag_counts'])
+	np.testing.assert_array_equal(np.bincount(table['ncat'], minlength=k + 1), g[prefix + 'ncat_counts'])
+	for c in FLOATCOLS:
+		np.testing.assert_allclose(np.sum(table[c]), g[prefix + 'sum_' + c][0], rtol=rtol, err_msg=c)
+	for i in range(k):
+		for j in range(i + 1, k):
+			np.testing.assert_allclose(np.nansum(table['Separation_%s_%s' % (names[i], names[j])]),
+				g[prefix + 'sum_sep_%d_%d' % (i, j)][0], rtol=rtol)
