@@ -1,0 +1,150 @@
+/* nwayhip.h -- C ABI of libnwayhip.so, the MI355X (gfx950) implementation of nway's
+ * match-probability hot path.
+ *
+ * The reference (JohannesBuchner/nway v4.7.1) is pure Python and has no FFI; the
+ * boundary is its Python surface.  Every entry point below names the reference
+ * interface (file:line in /root/reference) whose work it replaces; the Python host
+ * (nway_amd/) keeps the reference's function names and calls these through ctypes.
+ *
+ * Conventions
+ *   - every function returns int: 0 = ok, < 0 = error (text via nwayhip_last_error()).
+ *   - no C++ types, exceptions, torch types or Python objects cross this boundary.
+ *   - all array arguments are DEVICE pointers unless the name starts with h_.
+ *     The caller owns every buffer (the Python host passes torch.Tensor.data_ptr()).
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).  Calls
+ *     only enqueue work; nothing synchronises with the host.
+ *   - floating columns are double, SoA; catalogue row indices are int32 (N < 2^31).
+ */
+#ifndef NWAYHIP_H
+#define NWAYHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NWAYHIP_ABI_VERSION 1
+#define NWAYHIP_MAXCAT 8                 /* catalogues per match (primary + 7) */
+#define NWAYHIP_MAXPAIR 28               /* MAXCAT*(MAXCAT-1)/2 separation columns */
+
+/* candidate-cell scheme (fastskymatch.py:94-98) */
+#define NWAYHIP_SCHEME_FLAT 0            /* reference's flat RA/Dec cells, :123-133 */
+#define NWAYHIP_SCHEME_SPHERE 1          /* replaces the HEALPix branch :135-160 by its
+                                            post-filter result (all pairwise sep < radius) */
+
+/* unrelated-association correction */
+#define NWAYHIP_CORRECTION_NONE 0        /* == nwaylib.nway_match (__init__.py:262-301 is a no-op) */
+#define NWAYHIP_CORRECTION_CLI 1         /* nway.py:366-423 */
+
+/* status words written by nwayhip_match_enqueue (device int64[NWAYHIP_STATUS_WORDS]) */
+#define NWAYHIP_STATUS_WORDS 32
+#define NWAYHIP_ST_ROWS 0                /* M: rows of the match table */
+#define NWAYHIP_ST_FLAGS 1               /* bit mask, NWAYHIP_FLAG_* */
+#define NWAYHIP_ST_REGISTRATIONS 2       /* primary -> cell registrations */
+#define NWAYHIP_ST_TESTS 3               /* great-circle distance tests executed (M0') */
+#define NWAYHIP_ST_SURVIVORS 8           /* + c: secondaries of catalogue c passing the cell filter */
+#define NWAYHIP_ST_PAIRS 16              /* + c: (primary, secondary) links of catalogue c */
+#define NWAYHIP_ST_NOTFLAT 24            /* + c: 1 if catalogue c violates the flat-cell condition */
+
+#define NWAYHIP_FLAG_PAIR_OVERFLOW 1     /* cap_pairs too small: results invalid, retry larger */
+#define NWAYHIP_FLAG_ROW_OVERFLOW 2      /* cap_rows too small: results invalid, retry larger */
+#define NWAYHIP_FLAG_REG_OVERFLOW 4      /* registration table too small */
+
+typedef struct nwayhip_catalogue {
+	const double* ra;                    /* degrees */
+	const double* dec;                   /* degrees */
+	const double* sigma;                 /* positional error, arcsec (may be NULL if sigma_const > 0) */
+	double sigma_const;                  /* used when sigma == NULL */
+	int64_t n;
+} nwayhip_catalogue;
+
+typedef struct nwayhip_match_params {
+	int32_t ncat;                        /* 2..NWAYHIP_MAXCAT */
+	int32_t scheme;                      /* NWAYHIP_SCHEME_* (host decides as fastskymatch.py:94-98) */
+	int32_t radius_filter;               /* 1: keep rows with Separation_max < radius (__init__.py:180);
+	                                        0: raw crossproduct (fastskymatch.py:92-218; FLAT only) */
+	int32_t correction;                  /* NWAYHIP_CORRECTION_* */
+	int32_t finalize;                    /* 1: also run the per-primary group statistics with
+	                                        total = dist_bayesfactor (no magnitude biases) */
+	int32_t reserved;
+	double err_deg;                      /* cell size: match_radius / 60. / 60 (__init__.py:128) */
+	double radius_arcsec;                /* match_radius */
+	double prob_ratio_secondary;         /* __init__.py:33 */
+	double dens[NWAYHIP_MAXCAT];         /* nu_c      (__init__.py:199-217) */
+	double dens_plus[NWAYHIP_MAXCAT];    /* nu+_c */
+	/* prior for every presence pattern: bit (c-1) set <=> catalogue c present;
+	 * = nu_0 * prod(completeness[present]) / prod(nu+[present])  (__init__.py:254) */
+	double prior_table[1 << (NWAYHIP_MAXCAT - 1)];
+	double sphere_cell_factor;           /* all-sky cell edge in units of the radius (0 = default) */
+	int64_t bitmap_bits;                 /* 0 = default; power of two */
+} nwayhip_match_params;
+
+/* Output table, SoA, `capacity` rows allocated by the caller.  Columns follow
+ * __init__.py:133-177,100-111,405-418 / SURVEY.md appendix C. */
+typedef struct nwayhip_table {
+	int64_t capacity;
+	int32_t* idx[NWAYHIP_MAXCAT];        /* row index into catalogue c, -1 = absent */
+	double* sep[NWAYHIP_MAXPAIR];        /* Separation_{i}_{j}, i<j, order (0,1),(0,2)..(1,2)..; NaN if absent */
+	double* sep_max;                     /* Separation_max */
+	int8_t* ncat;
+	double* log_bf;                      /* dist_bayesfactor_uncorrected */
+	double* log_bf_corrected;            /* dist_bayesfactor (== log_bf unless correction CLI); may be NULL */
+	double* prior;
+	double* dist_post;
+	double* p_single;                    /* finalize only */
+	double* p_any;                       /* prob_has_match */
+	double* p_i;                         /* prob_this_match */
+	int8_t* match_flag;
+	int64_t* group_start;                /* [n_primary + 1] first row of every primary */
+} nwayhip_table;
+
+typedef struct nwayhip_plan nwayhip_plan;
+
+/* ---- library ---------------------------------------------------------------------- */
+int nwayhip_version(void);
+const char* nwayhip_last_error(void);
+int nwayhip_device_count(int* h_count);
+
+/* ---- elementwise mirrors of the reference's array functions ------------------------ */
+/* fastskymatch.py:26-47  dist(apos, bpos) -> degrees */
+int nwayhip_dist(const double* a_ra, const double* a_dec, const double* b_ra, const double* b_dec,
+	int64_t n, double* out_deg, void* stream);
+/* bayesdistance.py:64-86  log_bf(p, s).  h_sep: host array of ncat*ncat device pointers
+ * (row-major, only i<j read), h_sigma: host array of ncat device pointers. */
+int nwayhip_log_bf(int32_t ncat, int64_t n, const double* const* h_sep, const double* const* h_sigma,
+	double* out, void* stream);
+/* bayesdistance.py:26-32 (mode 0: posterior), :18-23 (mode 1: log_posterior),
+ * :35-39 (mode 2: unnormalised_log_posterior) */
+int nwayhip_posterior(int32_t mode, const double* prior, const double* log_bf, int64_t n, double* out, void* stream);
+
+/* ---- the match pipeline ------------------------------------------------------------ */
+/* Replaces crossproduct (fastskymatch.py:92-218), _create_match_table (__init__.py:123-196),
+ * _compute_single_log_bf (:220-259), posterior (:110) and, with finalize,
+ * _compute_final_probabilities (:399-461).
+ *
+ * A plan fixes the parameters, catalogue sizes and buffer capacities and carves the
+ * caller's workspace; it owns no device memory. */
+int nwayhip_plan_create(nwayhip_plan** plan, const nwayhip_match_params* params, const int64_t* h_n,
+	int64_t cap_pairs, int64_t cap_rows);
+int nwayhip_plan_destroy(nwayhip_plan* plan);
+size_t nwayhip_plan_workspace_bytes(const nwayhip_plan* plan);
+/* Enqueue the whole pipeline on `stream`.  d_status: device int64[NWAYHIP_STATUS_WORDS]. */
+int nwayhip_match_enqueue(nwayhip_plan* plan, const nwayhip_catalogue* h_cats, void* workspace,
+	size_t workspace_bytes, const nwayhip_table* h_table, int64_t* d_status, void* stream);
+
+/* Per-primary group statistics (__init__.py:399-461 == nway.py:527-586) on a table whose
+ * total = log_bf + sum(biases) was assembled by the caller (magnitude priors).
+ * group_start: int64[n_groups + 1].  Writes p_single, p_any, p_i, match_flag. */
+int nwayhip_group_stats(int64_t n_rows, int64_t n_groups, const int64_t* group_start, const double* total,
+	const double* prior, double prob_ratio_secondary, double* p_single, double* p_any, double* p_i,
+	int8_t* match_flag, void* stream);
+
+/* fastskymatch.py:94-98 on device-resident columns: out[0..3] = min ra, max ra, max |dec|, #NaN */
+int nwayhip_catalogue_extent(const double* ra, const double* dec, int64_t n, double* d_out4, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

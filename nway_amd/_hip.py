@@ -1,0 +1,279 @@
+"""ctypes binding of libnwayhip.so (include/nwayhip.h) and device-buffer plumbing.
+
+PyTorch-ROCm is used ONLY as the device allocator / stream provider: every buffer
+crossing the C ABI is a raw device pointer (``tensor.data_ptr()``).  There is no CPU
+fallback: if the HIP library or a GPU is missing, every compute entry point raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+import numpy
+
+from . import build as _build
+
+MAXCAT = 8
+MAXPAIR = 28
+STATUS_WORDS = 32
+ST_ROWS, ST_FLAGS, ST_REGISTRATIONS, ST_TESTS = 0, 1, 2, 3
+ST_SURVIVORS, ST_PAIRS, ST_NOTFLAT = 8, 16, 24
+FLAG_PAIR_OVERFLOW, FLAG_ROW_OVERFLOW, FLAG_REG_OVERFLOW = 1, 2, 4
+SCHEME_FLAT, SCHEME_SPHERE = 0, 1
+CORRECTION_NONE, CORRECTION_CLI = 0, 1
+
+
+class NwayHipError(RuntimeError):
+	pass
+
+
+class Catalogue(ctypes.Structure):
+	_fields_ = [('ra', ctypes.c_void_p), ('dec', ctypes.c_void_p), ('sigma', ctypes.c_void_p),
+		('sigma_const', ctypes.c_double), ('n', ctypes.c_int64)]
+
+
+class MatchParams(ctypes.Structure):
+	_fields_ = [('ncat', ctypes.c_int32), ('scheme', ctypes.c_int32), ('radius_filter', ctypes.c_int32),
+		('correction', ctypes.c_int32), ('finalize', ctypes.c_int32), ('reserved', ctypes.c_int32),
+		('err_deg', ctypes.c_double), ('radius_arcsec', ctypes.c_double), ('prob_ratio_secondary', ctypes.c_double),
+		('dens', ctypes.c_double * MAXCAT), ('dens_plus', ctypes.c_double * MAXCAT),
+		('prior_table', ctypes.c_double * (1 << (MAXCAT - 1))),
+		('sphere_cell_factor', ctypes.c_double), ('bitmap_bits', ctypes.c_int64)]
+
+
+class Table(ctypes.Structure):
+	_fields_ = [('capacity', ctypes.c_int64), ('idx', ctypes.c_void_p * MAXCAT), ('sep', ctypes.c_void_p * MAXPAIR),
+		('sep_max', ctypes.c_void_p), ('ncat', ctypes.c_void_p), ('log_bf', ctypes.c_void_p),
+		('log_bf_corrected', ctypes.c_void_p), ('prior', ctypes.c_void_p), ('dist_post', ctypes.c_void_p),
+		('p_single', ctypes.c_void_p), ('p_any', ctypes.c_void_p), ('p_i', ctypes.c_void_p),
+		('match_flag', ctypes.c_void_p), ('group_start', ctypes.c_void_p)]
+
+
+# every symbol include/nwayhip.h declares: (restype, argtypes)
+_vp, _i64, _i32, _dbl = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_double
+SYMBOLS = {
+	'nwayhip_version': (ctypes.c_int, []),
+	'nwayhip_last_error': (ctypes.c_char_p, []),
+	'nwayhip_device_count': (ctypes.c_int, [ctypes.POINTER(ctypes.c_int)]),
+	'nwayhip_dist': (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _vp, _vp]),
+	'nwayhip_log_bf': (ctypes.c_int, [_i32, _i64, ctypes.POINTER(_vp), ctypes.POINTER(_vp), _vp, _vp]),
+	'nwayhip_posterior': (ctypes.c_int, [_i32, _vp, _vp, _i64, _vp, _vp]),
+	'nwayhip_plan_create': (ctypes.c_int, [ctypes.POINTER(_vp), ctypes.POINTER(MatchParams), ctypes.POINTER(_i64), _i64, _i64]),
+	'nwayhip_plan_destroy': (ctypes.c_int, [_vp]),
+	'nwayhip_plan_workspace_bytes': (ctypes.c_size_t, [_vp]),
+	'nwayhip_match_enqueue': (ctypes.c_int, [_vp, ctypes.POINTER(Catalogue), _vp, ctypes.c_size_t, ctypes.POINTER(Table), _vp, _vp]),
+	'nwayhip_group_stats': (ctypes.c_int, [_i64, _i64, _vp, _vp, _vp, _dbl, _vp, _vp, _vp, _vp, _vp]),
+	'nwayhip_catalogue_extent': (ctypes.c_int, [_vp, _vp, _i64, _vp, _vp]),
+}
+
+_lib = None
+
+
+def library_path():
+	return _build.LIBRARY
+
+
+def load():
+	"""dlopen libnwayhip.so and bind the prototypes (works without a GPU)."""
+	global _lib
+	if _lib is not None:
+		return _lib
+	path = library_path()
+	if not os.path.exists(path):
+		raise NwayHipError('HIP library %s is not built; run "python -m nway_amd.build" (needs hipcc). '
+			'There is no CPU fallback.' % path)
+	lib = ctypes.CDLL(path)
+	for name, (restype, argtypes) in SYMBOLS.items():
+		fn = getattr(lib, name)
+		fn.restype = restype
+		fn.argtypes = argtypes
+	if lib.nwayhip_version() != 1:
+		raise NwayHipError('ABI version mismatch: library %d, binding 1' % lib.nwayhip_version())
+	_lib = lib
+	return lib
+
+
+def check(rc):
+	if rc != 0:
+		raise NwayHipError(load().nwayhip_last_error().decode('utf-8', 'replace'))
+
+
+def device_count():
+	n = ctypes.c_int(0)
+	rc = load().nwayhip_device_count(ctypes.byref(n))
+	return n.value if rc == 0 else 0
+
+
+_torch = None
+
+
+def torch():
+	global _torch
+	if _torch is None:
+		import torch as t
+		_torch = t
+	return _torch
+
+
+def require_device(device=None):
+	"""torch.device of the GPU to use; raises when there is none (no CPU fallback)."""
+	t = torch()
+	if not t.cuda.is_available() or device_count() < 1:
+		raise NwayHipError('no AMD GPU visible: the nway hot path runs only as HIP kernels (no CPU fallback)')
+	if device is None:
+		return t.device('cuda', t.cuda.current_device())
+	return t.device(device)
+
+
+def to_device(array, device, dtype=None):
+	"""numpy array or torch tensor -> contiguous device tensor (float64 by default)"""
+	t = torch()
+	dtype = dtype or t.float64
+	if isinstance(array, t.Tensor):
+		return array.to(device=device, dtype=dtype).contiguous()
+	a = numpy.ascontiguousarray(numpy.asarray(array), dtype={t.float64: numpy.float64, t.int32: numpy.int32, t.int64: numpy.int64}[dtype])
+	return t.from_numpy(a).to(device)
+
+
+def current_stream_ptr(device):
+	return ctypes.c_void_p(torch().cuda.current_stream(device).cuda_stream)
+
+
+def ptr(tensor):
+	return ctypes.c_void_p(tensor.data_ptr()) if tensor is not None else ctypes.c_void_p(0)
+
+
+def pair_columns(ncat):
+	return [(i, j) for i in range(ncat) for j in range(i + 1, ncat)]
+
+
+class DeviceCatalogue(object):
+	"""ra/dec (deg) and positional error (arcsec) columns resident in HBM."""
+
+	def __init__(self, ra, dec, error, device):
+		self.ra = to_device(ra, device)
+		self.dec = to_device(dec, device)
+		if numpy.ndim(error) == 0 and not isinstance(error, torch().Tensor):
+			self.sigma = None
+			self.sigma_const = float(error)
+		else:
+			self.sigma = to_device(error, device)
+			self.sigma_const = 0.0
+		self.n = int(self.ra.shape[0])
+		if self.dec.shape[0] != self.n or (self.sigma is not None and self.sigma.shape[0] != self.n):
+			raise ValueError('catalogue columns differ in length')
+
+	def struct(self):
+		return Catalogue(ptr(self.ra), ptr(self.dec), ptr(self.sigma), self.sigma_const, self.n)
+
+
+class MatchPlan(object):
+	"""Parameters + capacities + device buffers for repeated runs of the match pipeline."""
+
+	def __init__(self, sizes, params, cap_pairs, cap_rows, device):
+		t = torch()
+		self.lib = load()
+		self.device = require_device(device)
+		self.ncat = len(sizes)
+		self.sizes = [int(n) for n in sizes]
+		self.params = params
+		self.cap_pairs = int(cap_pairs)
+		self.cap_rows = int(cap_rows)
+		handle = ctypes.c_void_p(0)
+		n_arr = (ctypes.c_int64 * self.ncat)(*self.sizes)
+		check(self.lib.nwayhip_plan_create(ctypes.byref(handle), ctypes.byref(params), n_arr, self.cap_pairs, self.cap_rows))
+		self.handle = handle
+		self.workspace_bytes = int(self.lib.nwayhip_plan_workspace_bytes(handle))
+		with t.cuda.device(self.device):
+			self.workspace = t.empty(self.workspace_bytes + 256, dtype=t.uint8, device=self.device)
+			self.status = t.zeros(STATUS_WORDS, dtype=t.int64, device=self.device)
+			cap = self.cap_rows
+			f64 = lambda: t.empty(cap, dtype=t.float64, device=self.device)
+			self.cols = {}
+			self.cols['idx'] = [t.empty(cap, dtype=t.int32, device=self.device) for _ in range(self.ncat)]
+			self.cols['sep'] = [f64() for _ in pair_columns(self.ncat)]
+			for name in ('sep_max', 'log_bf', 'log_bf_corrected', 'prior', 'dist_post', 'p_single', 'p_any', 'p_i'):
+				self.cols[name] = f64()
+			self.cols['ncat'] = t.empty(cap, dtype=t.int8, device=self.device)
+			self.cols['match_flag'] = t.empty(cap, dtype=t.int8, device=self.device)
+			self.cols['group_start'] = t.empty(self.sizes[0] + 1, dtype=t.int64, device=self.device)
+		tab = Table()
+		tab.capacity = cap
+		for c in range(self.ncat):
+			tab.idx[c] = self.cols['idx'][c].data_ptr()
+		for p in range(len(self.cols['sep'])):
+			tab.sep[p] = self.cols['sep'][p].data_ptr()
+		for name in ('sep_max', 'ncat', 'log_bf', 'log_bf_corrected', 'prior', 'dist_post', 'p_single', 'p_any', 'p_i', 'match_flag', 'group_start'):
+			setattr(tab, name, self.cols[name].data_ptr())
+		self.table_struct = tab
+		ws = self.workspace.data_ptr()
+		self.ws_ptr = (ws + 255) // 256 * 256
+		self.ws_len = self.workspace_bytes + 256 - (self.ws_ptr - ws)
+
+	def enqueue(self, catalogues, stream=None):
+		"""enqueue one pass of the whole pipeline; does not synchronise"""
+		cats = (Catalogue * self.ncat)(*[c.struct() for c in catalogues])
+		s = stream if stream is not None else current_stream_ptr(self.device)
+		check(self.lib.nwayhip_match_enqueue(self.handle, cats, ctypes.c_void_p(self.ws_ptr), self.ws_len,
+			ctypes.byref(self.table_struct), ptr(self.status), s))
+
+	def read_status(self):
+		"""synchronises; returns the status words as numpy int64"""
+		return self.status.cpu().numpy()
+
+	def close(self):
+		if getattr(self, 'handle', None):
+			self.lib.nwayhip_plan_destroy(self.handle)
+			self.handle = None
+
+	def __del__(self):
+		try:
+			self.close()
+		except Exception:
+			pass
+
+
+def make_params(ncat, scheme, radius_arcsec, err_deg, dens, dens_plus, prior_table, prob_ratio_secondary=0.5,
+		radius_filter=True, correction=CORRECTION_NONE, finalize=True, sphere_cell_factor=0.0, bitmap_bits=0):
+	p = MatchParams()
+	p.ncat = ncat
+	p.scheme = scheme
+	p.radius_filter = 1 if radius_filter else 0
+	p.correction = correction
+	p.finalize = 1 if finalize else 0
+	p.err_deg = err_deg
+	p.radius_arcsec = radius_arcsec
+	p.prob_ratio_secondary = prob_ratio_secondary
+	for c in range(ncat):
+		p.dens[c] = dens[c]
+		p.dens_plus[c] = dens_plus[c]
+	for i, v in enumerate(prior_table):
+		p.prior_table[i] = v
+	p.sphere_cell_factor = sphere_cell_factor
+	p.bitmap_bits = bitmap_bits
+	return p
+
+
+def run_plan(sizes, params, catalogues, cap_pairs, cap_rows, device, max_retries=6):
+	"""enqueue, synchronise, grow the capacities on overflow; returns (plan, status)"""
+	for attempt in range(max_retries):
+		plan = MatchPlan(sizes, params, cap_pairs, cap_rows, device)
+		plan.enqueue(catalogues)
+		st = plan.read_status()
+		flags = int(st[ST_FLAGS])
+		if flags & FLAG_REG_OVERFLOW:
+			plan.close()
+			raise NwayHipError('primary cell registration overflowed (sources piled up on a pole?)')
+		if flags & (FLAG_PAIR_OVERFLOW | FLAG_ROW_OVERFLOW):
+			need_pairs = int(max(st[ST_PAIRS:ST_PAIRS + 8]))
+			cap_pairs = max(cap_pairs, int(need_pairs * 1.05) + 1024)
+			if flags & FLAG_ROW_OVERFLOW and not flags & FLAG_PAIR_OVERFLOW:
+				cap_rows = max(cap_rows * 2, int(st[ST_ROWS] * 1.05) + 1024)
+			elif flags & FLAG_ROW_OVERFLOW:
+				cap_rows = cap_rows * 2
+			plan.close()
+			del plan
+			torch().cuda.empty_cache()
+			continue
+		return plan, st
+	raise NwayHipError('match table capacity could not be settled after %d attempts' % max_retries)

@@ -1,0 +1,204 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the golden vectors produced
+by the reference and against the CPU oracle on seeded inputs.
+
+Contract (BASELINE.json north_star): index columns, ncat and match_flag bit-identical;
+floating columns within 1e-6 relative (tolerances in goldenutil.RTOL/ATOL).
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from goldenutil import (ROOT, golden, ell_tables, xmm_tables, assert_table_matches,
+	assert_checksums_match, idx_hash, cat, RTOL, ATOL)
+
+sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+import nway_oracle as orc  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def nw():
+	import nway_amd
+	from nway_amd import _hip
+	_hip.require_device()
+	return nway_amd
+
+
+def as_dict(df):
+	return dict((c, df[c].values) for c in df.columns)
+
+
+def run(nw, tables, radius, completeness, **kw):
+	return as_dict(nw.nway_match(tables, radius, completeness, logger=nw.NullOutputLogger(), **kw))
+
+
+def test_loaded_native_library(nw):
+	from nway_amd import _hip
+	lib = _hip.load()
+	assert lib.nwayhip_version() == 1
+	assert _hip.device_count() >= 1
+
+
+def test_dist_log_bf_posterior_known_answers(nw):
+	g = golden('kat_math')
+	d = nw.match.dist((53.15964508, -27.92927742), (53.15953445, -27.9313736))
+	assert d == pytest.approx(0.002098457623965017, rel=1e-9)
+	np.testing.assert_allclose(nw.match.dist((g['dist_ra'], g['dist_dec']), (g['dist_ra2'], g['dist_dec2'])), g['dist_array'], rtol=1e-9)
+	np.testing.assert_allclose(nw.match.dist((g['sph_a_ra'], g['sph_a_dec']), (g['sph_b_ra'], g['sph_b_dec'])), g['sph_dist'], rtol=RTOL, atol=1e-13)
+	bd = nw.bayesdist
+	# tests/bayesdistance_test.py:12-32 of the reference
+	for i, psi in enumerate(g['sep']):
+		a = bd.log_bf([[None, psi]], [0.1, 0.2])
+		np.testing.assert_almost_equal(bd.log_bf2(psi, 0.1, 0.2), a)
+		assert a == pytest.approx(g['log_bf_n2'][i], rel=1e-12)
+		b = bd.log_bf([[None, psi, psi], [psi, None, psi], [psi, psi, None]], [0.1, 0.2, 0.3])
+		np.testing.assert_almost_equal(bd.log_bf3(psi, psi, psi, 0.1, 0.2, 0.3), b)
+		assert b == pytest.approx(g['log_bf_n3'][i], rel=1e-12)
+	assert bd.log_bf([[None]], [0.5]) == 0.0
+	p4 = g['n4_sep']
+	got = bd.log_bf([[p4[i][j] for j in range(4)] for i in range(4)], list(g['n4_sigma']))
+	np.testing.assert_allclose(got, g['n4_log_bf'], rtol=1e-12)
+	np.testing.assert_allclose(bd.posterior(g['post_prior'], g['post_logbf']), g['posterior'], rtol=1e-10)
+	np.testing.assert_allclose(bd.log_posterior(g['post_prior'], g['post_logbf']), g['log_posterior'], rtol=1e-10, atol=1e-15)
+	np.testing.assert_allclose(bd.unnormalised_log_posterior(g['post_prior'], g['post_logbf'], 2), g['unnormalised_log_posterior'], rtol=1e-13)
+	assert bd.posterior(1e-3, 2.5) == pytest.approx(0.24043574366935122, rel=1e-12)
+
+
+def test_ell2_golden(nw):
+	X, R, O = ell_tables()
+	g = golden('ell2')
+	cp = nw.match.crossproduct([(X['ra'], X['dec']), (O['ra'], O['dec'])], 10. / 60 / 60)
+	np.testing.assert_array_equal(cp, g['crossproduct'])
+	names = [X['name'], O['name']]
+	t = run(nw, [X, O], 10., 1.0)
+	assert len(t['ncat']) == 37706
+	assert_table_matches(t, g, 'c10_', names)
+	assert_checksums_match(t, g, 'c10_', names, rtol=1e-7)
+	t9 = run(nw, [X, O], 10., 0.9)
+	np.testing.assert_array_equal(t9['match_flag'], g['c09_match_flag'])
+	assert t9['prob_has_match'][0] == pytest.approx(0.12830303519644448, rel=1e-9)
+	tt = run(nw, [X, O], 10., 0.9, prob_ratio_secondary=0.25, min_prob=0.01)
+	assert_table_matches(tt, g, 'trunc_', names)
+
+
+def test_ell3_golden(nw):
+	X, R, O = ell_tables()
+	g = golden('ell3')
+	tabs = [(t['ra'], t['dec']) for t in (X, R, O)]
+	cp = nw.match.crossproduct(tabs, 10. / 60 / 60)
+	assert len(cp) == 1831619
+	assert idx_hash(cp) == g['crossproduct_hash'][0]
+	names = [X['name'], R['name'], O['name']]
+	t = run(nw, [X, R, O], 10., 1.0)
+	assert len(t['ncat']) == 450435
+	assert_checksums_match(t, g, 'c10_', names, rtol=1e-7)
+	assert_table_matches(t, g, 'c10_sub_', names, rows=g['c10_sub_rows'])
+	np.testing.assert_array_equal(t['dist_bayesfactor'], t['dist_bayesfactor_uncorrected'])
+	# behaviour of the script's unrelated-association correction (nway.py:366-420)
+	tc = run(nw, [X, R, O], 10., 1.0, unrelated_associations='cli')
+	delta = tc['dist_bayesfactor'] - tc['dist_bayesfactor_uncorrected']
+	changed = np.flatnonzero(delta != 0)
+	np.testing.assert_array_equal(changed, g['cli_changed_rows'])
+	np.testing.assert_allclose(delta[changed], g['cli_correction'], rtol=1e-6)
+	assert delta.sum() == pytest.approx(23.903020785235466, rel=1e-7)
+
+
+def test_xmm_standins_golden(nw):
+	X, O, I = xmm_tables()
+	g = golden('xmm_syn')
+	t = run(nw, [X, O], 20., 0.9)
+	assert len(t['ncat']) == 44909
+	assert_table_matches(t, g, 'w2_', ['XMM', 'OPT'])
+	t3 = run(nw, [X, O, I], 20., 0.9)
+	assert len(t3['ncat']) == 449459
+	assert_checksums_match(t3, g, 'w3_', ['XMM', 'OPT', 'IRAC'], rtol=1e-7)
+	assert_table_matches(t3, g, 'w3_sub_', ['XMM', 'OPT', 'IRAC'], rows=g['w3_sub_rows'])
+
+
+def test_edge_cases_golden(nw):
+	g = golden('edge')
+	tabs = [cat('ABC'[i], g['neg_ra%d' % i], g['neg_dec%d' % i], g['neg_err%d' % i], g['neg_area'][0]) for i in range(3)]
+	cp = nw.match.crossproduct([(x['ra'], x['dec']) for x in tabs], float(g['neg_radius'][0]) / 60 / 60)
+	np.testing.assert_array_equal(cp, g['neg_crossproduct'])
+	t = run(nw, tabs, float(g['neg_radius'][0]), g['neg_completeness'])
+	assert_table_matches(t, g, 'neg_', ['A', 'B', 'C'])
+	tc = run(nw, tabs, float(g['neg_radius'][0]), g['neg_completeness'], unrelated_associations='cli')
+	delta = tc['dist_bayesfactor'] - tc['dist_bayesfactor_uncorrected']
+	np.testing.assert_array_equal(np.flatnonzero(delta != 0), g['neg_cli_changed_rows'])
+	np.testing.assert_allclose(delta[delta != 0], g['neg_cli_correction'], rtol=1e-6)
+	tp = cat('P', g['tie_p_ra'], g['tie_p_dec'], g['tie_p_err'], 1.0)
+	ts = cat('S', g['tie_s_ra'], g['tie_s_dec'], g['tie_s_err'], 1.0)
+	t = run(nw, [tp, ts], float(g['tie_radius'][0]), float(g['tie_completeness'][0]))
+	assert_table_matches(t, g, 'tie_', ['P', 'S'])
+	tp = cat('P', [g['hop_p'][0]], [g['hop_p'][1]], [g['hop_p'][2]], 1.0)
+	ts = cat('S', [g['hop_s'][0]], [g['hop_s'][1]], [g['hop_s'][2]], 1.0)
+	t = run(nw, [tp, ts], float(g['hop_radius'][0]), float(g['hop_completeness'][0]))
+	assert_table_matches(t, g, 'hop_', ['P', 'S'])
+	tabs = [cat('T%d' % i, g['k4_ra%d' % i], g['k4_dec%d' % i], g['k4_err%d' % i], g['k4_area'][0]) for i in range(4)]
+	t = run(nw, tabs, float(g['k4_radius'][0]), float(g['k4_completeness'][0]))
+	assert_table_matches(t, g, 'k4_', ['T0', 'T1', 'T2', 'T3'])
+
+
+def test_empty_secondary_catalogue(nw):
+	tp = cat('P', [10.0], [10.0], [1.0], 1.0)
+	ts = cat('S', np.zeros(0), np.zeros(0), np.zeros(0), 1.0)
+	t = run(nw, [tp, ts], 5., 0.9)
+	# a primary always keeps its no-counterpart row: one row, flagged 1
+	assert len(t['ncat']) == 1 and t['match_flag'][0] == 1 and t['prob_has_match'][0] == 0
+
+
+def oracle_vs_hip(nw, tabs, radius, completeness, names, **kw):
+	o = orc.nway_match(tabs, radius, completeness, **kw)
+	hk = dict(kw)
+	if hk.pop('correction', None) == 'cli':
+		hk['unrelated_associations'] = 'cli'
+	t = run(nw, tabs, radius, completeness, **hk)
+	k = len(names)
+	assert len(t['ncat']) == len(o['ncat'])
+	for n in names:
+		np.testing.assert_array_equal(t[n], o[n])
+	np.testing.assert_array_equal(t['ncat'], o['ncat'])
+	np.testing.assert_array_equal(t['match_flag'], o['match_flag'])
+	for i in range(k):
+		for j in range(i + 1, k):
+			c = 'Separation_%s_%s' % (names[i], names[j])
+			np.testing.assert_allclose(t[c], o[c], rtol=RTOL, atol=1e-9, equal_nan=True)
+	for c in ('Separation_max', 'dist_bayesfactor_uncorrected', 'dist_bayesfactor', 'dist_post', 'p_single', 'prob_has_match', 'prob_this_match'):
+		np.testing.assert_allclose(t[c], o[c], rtol=RTOL, atol=ATOL, err_msg=c)
+	return t
+
+
+def sphere_catalogue(rng, n, name, err, area=41252.96):
+	ra = rng.uniform(0, 360, size=n)
+	dec = np.degrees(np.arcsin(rng.uniform(-1, 1, size=n)))
+	return cat(name, ra, dec, err * np.ones(n), area)
+
+
+def test_sphere_scheme_vs_oracle(nw):
+	"""all-sky inputs incl. both poles and the RA = 0/360 seam (reference: HEALPix branch, which
+	no oracle here can execute -- compared with the oracle's definition, see oracle header)"""
+	rng = np.random.RandomState(5)
+	a = sphere_catalogue(rng, 3000, 'A', 20.)
+	b = sphere_catalogue(rng, 40000, 'B', 10.)
+	c = sphere_catalogue(rng, 30000, 'C', 15.)
+	for t, n in ((a, 300), (b, 3000), (c, 3000)):
+		t['ra'][:n] = rng.uniform(0, 360, size=n); t['dec'][:n] = 90 - np.abs(rng.normal(0, 0.2, size=n))
+		t['ra'][n:2 * n] = rng.uniform(0, 360, size=n); t['dec'][n:2 * n] = -90 + np.abs(rng.normal(0, 0.2, size=n))
+		t['ra'][2 * n:3 * n] = rng.normal(0, 0.15, size=n) % 360; t['dec'][2 * n:3 * n] = rng.normal(10, 0.15, size=n)
+	a['dec'][0] = 90.0; a['dec'][1] = -90.0; a['ra'][2] = 0.0; a['ra'][3] = 359.9999999
+	t = oracle_vs_hip(nw, [a, b], 120., 0.8, ['A', 'B'])
+	assert (t['B'] >= 0).sum() > 500
+	t = oracle_vs_hip(nw, [a, b, c], 120., 0.8, ['A', 'B', 'C'], correction='cli')
+	assert ((t['B'] >= 0) & (t['C'] >= 0)).sum() > 50
+
+
+def test_flat_scheme_random_vs_oracle(nw):
+	rng = np.random.RandomState(8)
+	def patch(n, name, err):
+		return cat(name, rng.uniform(40, 41.5, size=n), rng.uniform(-1.0, 0.8, size=n), rng.uniform(0.5 * err, err, size=n), 2.7)
+	a, b, c, d = patch(2000, 'A', 3.), patch(60000, 'B', 1.), patch(50000, 'C', 2.), patch(20000, 'D', 1.5)
+	oracle_vs_hip(nw, [a, b], 25., 0.9, ['A', 'B'])
+	oracle_vs_hip(nw, [a, b, c, d], 25., np.array([1.0, 0.9, 0.8, 0.7]), ['A', 'B', 'C', 'D'], correction='cli')
