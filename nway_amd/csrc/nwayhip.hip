@@ -1265,7 +1265,7 @@ int nwayhip_match_enqueue(nwayhip_plan* pl, const nwayhip_catalogue* h_cats, voi
 	for (int c = 0; c < k; ++c) {
 		if (h_cats[c].n != pl->n[c]) return fail("catalogue %d has %lld rows, plan was made for %lld", c, (long long)h_cats[c].n, (long long)pl->n[c]);
 		if (pl->n[c] > 0 && (!h_cats[c].ra || !h_cats[c].dec)) return fail("catalogue %d: null coordinates", c);
-		if (!h_cats[c].sigma && !(h_cats[c].sigma_const > 0)) return fail("catalogue %d: no positional error", c);
+		if (pl->n[c] > 0 && !h_cats[c].sigma && !(h_cats[c].sigma_const > 0)) return fail("catalogue %d: no positional error", c);
 		if (((uintptr_t)h_cats[c].ra & 15) || ((uintptr_t)h_cats[c].dec & 15)) return fail("catalogue %d: coordinate columns must be 16-byte aligned", c);
 		cats.c[c].ra = h_cats[c].ra;
 		cats.c[c].dec = h_cats[c].dec;
