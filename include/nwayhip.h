@@ -134,6 +134,23 @@ size_t nwayhip_plan_workspace_bytes(const nwayhip_plan* plan);
 int nwayhip_match_enqueue(nwayhip_plan* plan, const nwayhip_catalogue* h_cats, void* workspace,
 	size_t workspace_bytes, const nwayhip_table* h_table, int64_t* d_status, void* stream);
 
+/* Stage timing with HIP events recorded on the pipeline's own stream (bench.py's roofline leg).
+ * stage_mask: bit s set => every launch group of stage s in subsequent nwayhip_match_enqueue
+ * calls is bracketed by an event pair (ring of NWAYHIP_PROFILE_RING pairs per stage).
+ * nwayhip_plan_profile_read waits for the recorded events, returns per stage the number of
+ * bracketed launch groups and their summed duration in ms, and resets the counters. */
+#define NWAYHIP_STAGE_REGISTER 0
+#define NWAYHIP_STAGE_SWEEP 1
+#define NWAYHIP_STAGE_PAIRS 2
+#define NWAYHIP_STAGE_LISTS 3
+#define NWAYHIP_STAGE_EXPAND 4
+#define NWAYHIP_STAGE_ROWS 5
+#define NWAYHIP_STAGE_GROUPS 6
+#define NWAYHIP_STAGES 8
+#define NWAYHIP_PROFILE_RING 512
+int nwayhip_plan_profile(nwayhip_plan* plan, uint32_t stage_mask);
+int nwayhip_plan_profile_read(nwayhip_plan* plan, int64_t* h_launches /*[NWAYHIP_STAGES]*/, double* h_ms /*[NWAYHIP_STAGES]*/);
+
 /* Per-primary group statistics (__init__.py:399-461 == nway.py:527-586) on a table whose
  * total = log_bf + sum(biases) was assembled by the caller (magnitude priors).
  * group_start: int64[n_groups + 1].  Writes p_single, p_any, p_i, match_flag. */

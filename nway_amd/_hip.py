@@ -20,6 +20,8 @@ ST_ROWS, ST_FLAGS, ST_REGISTRATIONS, ST_TESTS = 0, 1, 2, 3
 ST_SURVIVORS, ST_PAIRS, ST_NOTFLAT = 8, 16, 24
 FLAG_PAIR_OVERFLOW, FLAG_ROW_OVERFLOW, FLAG_REG_OVERFLOW = 1, 2, 4
 SCHEME_FLAT, SCHEME_SPHERE = 0, 1
+STAGES = 8
+STAGE_NAMES = ['register', 'sweep', 'pairs', 'lists', 'expand', 'rows', 'groups']
 CORRECTION_NONE, CORRECTION_CLI = 0, 1
 
 
@@ -62,6 +64,8 @@ SYMBOLS = {
 	'nwayhip_plan_destroy': (ctypes.c_int, [_vp]),
 	'nwayhip_plan_workspace_bytes': (ctypes.c_size_t, [_vp]),
 	'nwayhip_match_enqueue': (ctypes.c_int, [_vp, ctypes.POINTER(Catalogue), _vp, ctypes.c_size_t, ctypes.POINTER(Table), _vp, _vp]),
+	'nwayhip_plan_profile': (ctypes.c_int, [_vp, ctypes.c_uint32]),
+	'nwayhip_plan_profile_read': (ctypes.c_int, [_vp, ctypes.POINTER(_i64), ctypes.POINTER(_dbl)]),
 	'nwayhip_group_stats': (ctypes.c_int, [_i64, _i64, _vp, _vp, _vp, _dbl, _vp, _vp, _vp, _vp, _vp]),
 	'nwayhip_catalogue_extent': (ctypes.c_int, [_vp, _vp, _i64, _vp, _vp]),
 }
@@ -216,6 +220,17 @@ class MatchPlan(object):
 		s = stream if stream is not None else current_stream_ptr(self.device)
 		check(self.lib.nwayhip_match_enqueue(self.handle, cats, ctypes.c_void_p(self.ws_ptr), self.ws_len,
 			ctypes.byref(self.table_struct), ptr(self.status), s))
+
+	def profile(self, stage_mask):
+		"""bracket the stages in ``stage_mask`` with HIP events on the pipeline's stream"""
+		check(self.lib.nwayhip_plan_profile(self.handle, stage_mask))
+
+	def profile_read(self):
+		"""(launch groups, summed ms) per stage since the last call; waits for the events"""
+		n = (ctypes.c_int64 * STAGES)()
+		ms = (ctypes.c_double * STAGES)()
+		check(self.lib.nwayhip_plan_profile_read(self.handle, n, ms))
+		return list(n), list(ms)
 
 	def read_status(self):
 		"""synchronises; returns the status words as numpy int64"""

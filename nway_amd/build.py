@@ -16,7 +16,8 @@ CSRC = os.path.join(HERE, 'csrc')
 INCLUDE = os.path.join(ROOT, 'include')
 LIBRARY = os.path.join(CSRC, 'libnwayhip.so')
 SOURCES = [os.path.join(CSRC, 'nwayhip.hip')]
-HEADERS = [os.path.join(INCLUDE, 'nwayhip.h')]
+HEADERS = [os.path.join(INCLUDE, 'nwayhip.h')] + sorted(
+	os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.inc'))
 ARCH = 'gfx950'
 
 
@@ -39,7 +40,7 @@ def build_library(force=False, verbose=False):
 	if not force and not is_stale():
 		return LIBRARY
 	cmd = [hipcc_path(), '--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-shared',
-		'-I' + INCLUDE, '-Wall', '-Wno-unused-function'] + SOURCES + ['-o', LIBRARY + '.tmp']
+		'-I' + INCLUDE, '-I' + CSRC, '-Wall', '-Wno-unused-function'] + SOURCES + ['-o', LIBRARY + '.tmp']
 	if verbose:
 		print(' '.join(cmd))
 	res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True)

@@ -15,6 +15,7 @@ from goldenutil import (ROOT, golden, ell_tables, xmm_tables, assert_table_match
 
 sys.path.insert(0, os.path.join(ROOT, 'oracle'))
 import nway_oracle as orc  # noqa: E402
+import nway_oracle_c as orc_c  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 
@@ -150,8 +151,8 @@ def test_empty_secondary_catalogue(nw):
 	assert len(t['ncat']) == 1 and t['match_flag'][0] == 1 and t['prob_has_match'][0] == 0
 
 
-def oracle_vs_hip(nw, tabs, radius, completeness, names, **kw):
-	o = orc.nway_match(tabs, radius, completeness, **kw)
+def oracle_vs_hip(nw, tabs, radius, completeness, names, oracle=orc, **kw):
+	o = oracle.nway_match(tabs, radius, completeness, **kw)
 	hk = dict(kw)
 	if hk.pop('correction', None) == 'cli':
 		hk['unrelated_associations'] = 'cli'
@@ -189,9 +190,10 @@ def test_sphere_scheme_vs_oracle(nw):
 		t['ra'][n:2 * n] = rng.uniform(0, 360, size=n); t['dec'][n:2 * n] = -90 + np.abs(rng.normal(0, 0.2, size=n))
 		t['ra'][2 * n:3 * n] = rng.normal(0, 0.15, size=n) % 360; t['dec'][2 * n:3 * n] = rng.normal(10, 0.15, size=n)
 	a['dec'][0] = 90.0; a['dec'][1] = -90.0; a['ra'][2] = 0.0; a['ra'][3] = 359.9999999
-	t = oracle_vs_hip(nw, [a, b], 120., 0.8, ['A', 'B'])
+	# the C restatement of the oracle (pinned against the numpy one in tests/test_oracle_c.py)
+	t = oracle_vs_hip(nw, [a, b], 120., 0.8, ['A', 'B'], oracle=orc_c)
 	assert (t['B'] >= 0).sum() > 500
-	t = oracle_vs_hip(nw, [a, b, c], 120., 0.8, ['A', 'B', 'C'], correction='cli')
+	t = oracle_vs_hip(nw, [a, b, c], 120., 0.8, ['A', 'B', 'C'], oracle=orc_c, correction='cli')
 	assert ((t['B'] >= 0) & (t['C'] >= 0)).sum() > 50
 
 
@@ -199,6 +201,6 @@ def test_flat_scheme_random_vs_oracle(nw):
 	rng = np.random.RandomState(8)
 	def patch(n, name, err):
 		return cat(name, rng.uniform(40, 41.5, size=n), rng.uniform(-1.0, 0.8, size=n), rng.uniform(0.5 * err, err, size=n), 2.7)
-	a, b, c, d = patch(2000, 'A', 3.), patch(60000, 'B', 1.), patch(50000, 'C', 2.), patch(20000, 'D', 1.5)
+	a, b, c, d = patch(800, 'A', 3.), patch(30000, 'B', 1.), patch(25000, 'C', 2.), patch(10000, 'D', 1.5)
 	oracle_vs_hip(nw, [a, b], 25., 0.9, ['A', 'B'])
 	oracle_vs_hip(nw, [a, b, c, d], 25., np.array([1.0, 0.9, 0.8, 0.7]), ['A', 'B', 'C', 'D'], correction='cli')

@@ -1,0 +1,66 @@
+"""Pin the C restatement of the oracle (oracle/nway_oracle.c, the cpu_baseline of bench.py)
+against the golden vectors generated from the reference."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from goldenutil import ROOT, golden, ell_tables, xmm_tables, assert_table_matches, assert_checksums_match, cat
+
+sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+import nway_oracle as orc  # noqa: E402
+import nway_oracle_c as orc_c  # noqa: E402
+
+# C libm vs numpy's SIMD loops: a few ulp
+TIGHT = dict(rtol=1e-11, atol=1e-13)
+
+
+def test_c_dist_known_answer():
+	lib = orc_c.load()
+	assert lib.nwayo_dist(53.15964508, -27.92927742, 53.15953445, -27.9313736) == pytest.approx(0.002098457623965017, rel=1e-12)
+
+
+def test_c_ell2_and_ell3():
+	X, R, O = ell_tables()
+	g = golden('ell2')
+	t = orc_c.nway_match([X, O], 10., 1.0)
+	assert_table_matches(t, g, 'c10_', [X['name'], O['name']], **TIGHT)
+	g3 = golden('ell3')
+	names = [X['name'], R['name'], O['name']]
+	t3 = orc_c.nway_match([X, R, O], 10., 1.0, correction='cli')
+	delta = t3['dist_bayesfactor'] - t3['dist_bayesfactor_uncorrected']
+	np.testing.assert_array_equal(np.flatnonzero(delta != 0), g3['cli_changed_rows'])
+	np.testing.assert_allclose(delta[delta != 0], g3['cli_correction'], rtol=1e-10)
+	t3 = orc_c.nway_match([X, R, O], 10., 1.0)
+	assert_checksums_match(t3, g3, 'c10_', names)
+	assert_table_matches(t3, g3, 'c10_sub_', names, rows=g3['c10_sub_rows'], **TIGHT)
+
+
+def test_c_xmm_and_edges():
+	X, O, I = xmm_tables()
+	g = golden('xmm_syn')
+	t = orc_c.nway_match([X, O], 20., 0.9)
+	assert_table_matches(t, g, 'w2_', ['XMM', 'OPT'], **TIGHT)
+	g = golden('edge')
+	tabs = [cat('ABC'[i], g['neg_ra%d' % i], g['neg_dec%d' % i], g['neg_err%d' % i], g['neg_area'][0]) for i in range(3)]
+	t = orc_c.nway_match(tabs, float(g['neg_radius'][0]), g['neg_completeness'])
+	assert_table_matches(t, g, 'neg_', ['A', 'B', 'C'], **TIGHT)
+	tabs = [cat('T%d' % i, g['k4_ra%d' % i], g['k4_dec%d' % i], g['k4_err%d' % i], g['k4_area'][0]) for i in range(4)]
+	t = orc_c.nway_match(tabs, float(g['k4_radius'][0]), float(g['k4_completeness'][0]))
+	assert_table_matches(t, g, 'k4_', ['T0', 'T1', 'T2', 'T3'], **TIGHT)
+
+
+def test_c_sphere_equals_numpy_oracle():
+	rng = np.random.RandomState(12)
+	def sph(n, name, err):
+		return cat(name, rng.uniform(0, 360, size=n), np.degrees(np.arcsin(rng.uniform(-1, 1, size=n))), err * np.ones(n), 41252.96)
+	a, b = sph(2000, 'A', 30.), sph(30000, 'B', 20.)
+	a['dec'][:50] = 90 - np.abs(rng.normal(0, 0.3, 50)); b['dec'][:500] = 90 - np.abs(rng.normal(0, 0.3, 500))
+	want = orc.nway_match([a, b], 400., 0.9)
+	got = orc_c.nway_match([a, b], 400., 0.9)
+	for c in ('A', 'B', 'match_flag', 'ncat'):
+		np.testing.assert_array_equal(got[c], want[c])
+	for c in ('Separation_A_B', 'dist_bayesfactor', 'prob_has_match', 'prob_this_match'):
+		np.testing.assert_allclose(got[c], want[c], equal_nan=True, **TIGHT)
+	assert (got['B'] >= 0).sum() > 100
