@@ -105,22 +105,33 @@ def main():
 	world = int(os.environ.get('WORLD_SIZE', '1'))
 	rank = int(os.environ.get('RANK', '0'))
 	local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+	ngpu = max(torch.cuda.device_count(), 1)
 	if world > 1:
 		import torch.distributed as dist
-		torch.cuda.set_device(local_rank)
-		dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+		# "nccl" is RCCL on ROCm.  NWAY_BENCH_BACKEND=gloo lets several ranks share one GPU
+		# (functional testing of the sharded path on a 1-GPU box only).
+		backend = os.environ.get('NWAY_BENCH_BACKEND', 'nccl')
+		torch.cuda.set_device(local_rank % ngpu)
+		if backend == 'nccl':
+			dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank % ngpu))
+		else:
+			dist.init_process_group(backend)
 	if args.gpus != world:
 		if rank == 0:
 			sys.stderr.write('note: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE\n' % (args.gpus, world))
-	device = torch.device('cuda', local_rank if world > 1 else 0)
+	device = torch.device('cuda', (local_rank % ngpu) if world > 1 else 0)
 	torch.cuda.set_device(device)
 
 	# weak scaling: every rank owns n_primary primaries (a contiguous row shard of the global
-	# primary catalogue) and a 1/world slice of the secondary catalogue
-	primary, secondary = make_workload(args.n_primary, args.n_secondary, args.seed + 1000 * rank)
+	# primary catalogue, N x n_primary rows) and loads a 1/world slice of the ONE secondary
+	# catalogue (n_secondary rows in total); the slices are all-gathered once at set-up so that
+	# every GPU holds the whole secondary catalogue, then each step matches the rank's primary
+	# shard against it -- per-GPU work is fixed, no collective on the per-step path.
+	n_sec_local = args.n_secondary // world + (args.n_secondary % world if rank == world - 1 else 0)
+	primary, secondary = make_workload(args.n_primary, n_sec_local, args.seed + 1000 * rank)
 	if world > 1:
 		from nway_amd import distributed
-		engine = distributed.ShardedMatch(primary, secondary, args.radius, args.completeness, device)
+		engine = distributed.ShardedMatch(primary, [secondary], args.radius, args.completeness, device)
 	else:
 		engine = None
 
@@ -148,9 +159,10 @@ def main():
 		plan = engine.plan
 
 	def barrier():
+		torch.cuda.synchronize(device)
 		if world > 1:
 			dist.barrier()
-		torch.cuda.synchronize(device)
+			torch.cuda.synchronize(device)
 
 	for _ in range(args.warmup):
 		step()
@@ -190,10 +202,14 @@ def main():
 		out = dict(metric='candidate Bayes-factor evals/s', value=rows_per_step / (ms_per_step * 1e-3), unit='candidate evaluations/s',
 			n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=ms_per_step, higher_is_better=True, scaling='weak',
 			vs_baseline=None, dtype='f64', data='synthetic',
-			config=dict(workload='C3-S synthetic 2-way: %d primary x %d secondary per GPU, uniform sky, radius %g arcsec, completeness %g, seed %d'
-				% (args.n_primary, args.n_secondary, args.radius, args.completeness, args.seed),
-				rows_per_step=rows_per_step, distance_tests_per_step=int(st[_hip.ST_TESTS]),
-				survivors_per_step=int(st[_hip.ST_SURVIVORS]), parallelism='primary-row shards x%d' % world),
+			config=dict(workload='C3-S synthetic 2-way: %d primaries per GPU (%d in total) x %d secondaries (whole catalogue resident on every GPU), '
+				'uniform sky, radius %g arcsec, completeness %g, seed %d'
+				% (args.n_primary, args.n_primary * world, n_sec_swept, args.radius, args.completeness, args.seed),
+				rows_per_step=rows_per_step, distance_tests_per_step_rank0=int(st[_hip.ST_TESTS]),
+				survivors_per_step_rank0=int(st[_hip.ST_SURVIVORS]), registrations_rank0=int(st[_hip.ST_REGISTRATIONS]),
+				parallelism='primary-row shards x%d' % world,
+				setup_allgatherv=(None if engine is None else dict(seconds=engine.setup_seconds, bytes=engine.gathered_bytes,
+					note='one-time all-gatherv of the secondary columns (RCCL), outside the timed steps'))),
 			roofline=dict(bound='hbm', kernel='k_sweep', achieved=achieved, peak=HBM_PEAK_GBS, unit='GB/s',
 				frac=achieved / HBM_PEAK_GBS, traffic=traffic, algorithmic_bytes_per_launch=alg_bytes,
 				launch_ms=sweep_ms, launches_timed=int(launches[1])))

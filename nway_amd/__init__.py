@@ -50,18 +50,23 @@ def choose_scheme(radectables, err):
 	return _hip.SCHEME_FLAT
 
 
-def _compute_source_densities(match_tables, logger):
-	"""nu_c and nu+_c, __init__.py:199-217."""
+def _densities_from_sizes(names, sizes, areas, logger):
+	"""nu_c = N_c / area_c * whole sky, nu+_c = (N_c + 1) / area_c * whole sky, nu+_0 = nu_0."""
 	dens, dens_plus = [], []
-	for i, t in enumerate(match_tables):
-		n = len(t['ra'])
-		area = t['area'] * 1.0
+	for i, (name, n, area) in enumerate(zip(names, sizes, areas)):
+		area = area * 1.0
 		density = n / area * AREA_TOTAL
-		logger.log('%s "%s" (%d), density gives %.2e objects on entire sky' % ('Primary catalogue' if i == 0 else 'Catalogue', t['name'], n, density))
+		logger.log('%s "%s" (%d), density gives %.2e objects on entire sky' % ('Primary catalogue' if i == 0 else 'Catalogue', name, n, density))
 		dens.append(density)
 		dens_plus.append((n + 1) / area * AREA_TOTAL)
 	dens_plus[0] = dens[0]
 	return numpy.array(dens), numpy.array(dens_plus)
+
+
+def _compute_source_densities(match_tables, logger):
+	"""nu_c and nu+_c of the catalogues, __init__.py:199-217."""
+	return _densities_from_sizes([t['name'] for t in match_tables], [len(t['ra']) for t in match_tables],
+		[t['area'] for t in match_tables], logger)
 
 
 def _completeness_vector(prior_completeness, ncats):

@@ -151,6 +151,23 @@ def pair_columns(ncat):
 	return [(i, j) for i in range(ncat) for j in range(i + 1, ncat)]
 
 
+def catalogue_extent(ra, dec):
+	"""(min ra, max ra, max |dec|, #NaN) of device-resident columns (k_extent); synchronises"""
+	t = torch()
+	out = t.empty(4, dtype=t.float64, device=ra.device)
+	check(load().nwayhip_catalogue_extent(ptr(ra), ptr(dec), int(ra.shape[0]), ptr(out), current_stream_ptr(ra.device)))
+	lo, hi, absdec, nnan = out.cpu().numpy()
+	return float(lo), float(hi), float(absdec), int(nnan)
+
+
+def scheme_from_extents(extents, err):
+	"""flat-cell condition of fastskymatch.py:94-98 evaluated on per-catalogue extents"""
+	for lo, hi, absdec, nnan in extents:
+		if not (err < 1 and lo > 10 * err and hi < 360 - 10 * err and absdec < 45):
+			return SCHEME_SPHERE
+	return SCHEME_FLAT
+
+
 class DeviceCatalogue(object):
 	"""ra/dec (deg) and positional error (arcsec) columns resident in HBM."""
 

@@ -1,0 +1,246 @@
+"""Multi-GPU sharding of the match: one process per GPU, torch.distributed (backend
+"nccl" = RCCL over xGMI on the GPU box, "gloo" for the CPU tests).
+
+The unit of work is the primary source: every output row belongs to exactly one primary
+and p_any / p_i / match_flag reduce only within a primary's rows (__init__.py:459,
+nway.py:547), so the primary catalogue is sharded by contiguous row ranges and each rank
+produces the corresponding contiguous block of the global match table.  Priors depend on
+the secondary densities only (nu_0 cancels against nu+_0 = nu_0, __init__.py:214,254), so
+a shard's rows are bit-identical to the same rows of the unsharded run.
+
+The one exchange step is the distribution of the secondary catalogues: each rank loads a
+slice and an all-gatherv (grouped broadcasts; RCCL has no native allgatherv) leaves the
+full ra / dec / error columns resident on every GPU.  It happens once per catalogue, not
+once per primary batch; ``ShardedMatch.setup`` times it separately.  No collective is on
+the per-batch path; the host concatenates per-rank tables in rank order when a global
+table is wanted.
+"""
+from __future__ import division, print_function
+
+import time
+
+import numpy
+
+
+def _dist():
+	import torch.distributed as dist
+	return dist
+
+
+def world_info(group=None):
+	dist = _dist()
+	if dist.is_available() and dist.is_initialized():
+		return dist.get_rank(group), dist.get_world_size(group)
+	return 0, 1
+
+
+def allgatherv(tensor, group=None):
+	"""Concatenation over ranks (rank order) of 1-D tensors of different lengths.
+	Returns (full tensor, list of per-rank counts)."""
+	import torch
+	dist = _dist()
+	rank, world = world_info(group)
+	if world == 1:
+		return tensor, [int(tensor.shape[0])]
+	count = torch.tensor([tensor.shape[0]], dtype=torch.int64, device=tensor.device)
+	counts = [torch.zeros(1, dtype=torch.int64, device=tensor.device) for _ in range(world)]
+	dist.all_gather(counts, count, group=group)
+	counts = [int(c.item()) for c in counts]
+	full = torch.empty(sum(counts), dtype=tensor.dtype, device=tensor.device)
+	offsets = numpy.concatenate([[0], numpy.cumsum(counts)])
+	pieces = [full[offsets[r]:offsets[r + 1]] for r in range(world)]
+	if dist.get_backend(group) == 'nccl':
+		# uneven all_gather = one coalesced group of broadcasts inside RCCL
+		dist.all_gather(pieces, tensor.contiguous(), group=group)
+	else:
+		pieces[rank].copy_(tensor)
+		works = []
+		for r in range(world):
+			if counts[r] > 0:
+				src = r if group is None else dist.get_global_rank(group, r)
+				works.append(dist.broadcast(pieces[r], src=src, group=group, async_op=True))
+		for w in works:
+			w.wait()
+	return full, counts
+
+
+def shard_bounds(n, world):
+	"""contiguous, balanced row ranges: rank r owns [bounds[r], bounds[r+1])"""
+	base, extra = divmod(n, world)
+	sizes = [base + (1 if r < extra else 0) for r in range(world)]
+	return numpy.concatenate([[0], numpy.cumsum(sizes)]).astype(numpy.int64)
+
+
+class ShardedMatch(object):
+	"""Primary rows sharded over the ranks, secondary catalogues replicated by all-gatherv.
+
+	primary: this rank's shard of the primary catalogue (dict: name, ra, dec, error, area)
+	secondaries: list of this rank's SLICES of the secondary catalogues (same dict layout;
+	  ``error`` may be a scalar)
+	compute: None = the HIP pipeline (needs a GPU); tests pass a callable
+	  ``compute(match_tables, match_radius, prior_completeness, **options) -> dict of columns``
+	  to exercise the sharding logic with gloo on CPU.
+	"""
+
+	def __init__(self, primary, secondaries, match_radius, prior_completeness, device, group=None,
+			prob_ratio_secondary=0.5, compute=None):
+		if isinstance(secondaries, dict):
+			secondaries = [secondaries]
+		self.primary = primary
+		self.secondary_slices = secondaries
+		self.match_radius = float(match_radius)
+		self.prior_completeness = prior_completeness
+		self.prob_ratio_secondary = prob_ratio_secondary
+		self.device = device
+		self.group = group
+		self.compute = compute
+		self.rank, self.world = world_info(group)
+		self.plan = None
+		self.setup_seconds = None
+		self.setup()
+
+	# -- one-time exchange ---------------------------------------------------------------
+	def setup(self):
+		import torch
+		dist = _dist()
+		t0 = time.perf_counter()
+		dev = self.device if self.compute is None else torch.device('cpu')
+		self.full_secondaries = []
+		self.gathered_bytes = 0
+		for sl in self.secondary_slices:
+			ra, _ = allgatherv(torch.as_tensor(numpy.asarray(sl['ra'], dtype=float)).to(dev), self.group)
+			dec, counts = allgatherv(torch.as_tensor(numpy.asarray(sl['dec'], dtype=float)).to(dev), self.group)
+			self.gathered_bytes += 16 * int(ra.shape[0])
+			if numpy.ndim(sl['error']) == 0:
+				err = float(sl['error'])
+			else:
+				err, _ = allgatherv(torch.as_tensor(numpy.asarray(sl['error'], dtype=float)).to(dev), self.group)
+				self.gathered_bytes += 8 * int(ra.shape[0])
+			self.full_secondaries.append(dict(name=sl['name'], ra=ra, dec=dec, error=err, area=sl['area'], counts=counts))
+		# global size of the primary catalogue (only logged; the priors do not depend on it)
+		n0 = torch.tensor([len(self.primary['ra'])], dtype=torch.int64, device=dev)
+		if self.world > 1:
+			sizes = [torch.zeros_like(n0) for _ in range(self.world)]
+			dist.all_gather(sizes, n0, group=self.group)
+			self.primary_sizes = [int(s.item()) for s in sizes]
+		else:
+			self.primary_sizes = [int(n0.item())]
+		self.primary_offset = int(sum(self.primary_sizes[:self.rank]))
+		if self.compute is None:
+			torch.cuda.synchronize(self.device)
+		self.setup_seconds = time.perf_counter() - t0
+		if self.compute is None:
+			self._build_plan()
+
+	def _tables(self):
+		"""match_tables of this rank: own primary shard + complete secondaries"""
+		sec = []
+		for f in self.full_secondaries:
+			e = f['error']
+			sec.append(dict(name=f['name'], ra=f['ra'], dec=f['dec'], error=e, area=f['area'], mags=[], maghists=[], magnames=[]))
+		prim = dict(self.primary)
+		# density of the WHOLE primary catalogue: scale the area of the shard
+		total = float(sum(self.primary_sizes))
+		prim['area'] = self.primary['area'] * (len(self.primary['ra']) / total) if total > 0 else self.primary['area']
+		return [prim] + sec
+
+	def _build_plan(self):
+		import nway_amd
+		from nway_amd import _hip
+		tables = self._tables()
+		log = nway_amd.NullOutputLogger()
+		k = len(tables)
+		err = self.match_radius / 60. / 60
+		# the flat-vs-all-sky decision needs every catalogue's extent: primaries are sharded, so
+		# the decision is made per rank and then agreed on (all-sky wins)
+		scheme = nway_amd.choose_scheme([(numpy.asarray(self.primary['ra'], dtype=float), numpy.asarray(self.primary['dec'], dtype=float))], err)
+		if scheme == _hip.SCHEME_FLAT:
+			scheme = _hip.scheme_from_extents([_hip.catalogue_extent(t['ra'], t['dec']) for t in tables[1:]], err)
+		if self.world > 1:
+			import torch
+			s = torch.tensor([scheme], dtype=torch.int64, device=self.device)
+			_dist().all_reduce(s, op=_dist().ReduceOp.MAX, group=self.group)
+			scheme = int(s.item())
+		self.scheme = scheme
+		dens, dens_plus = nway_amd._densities_from_sizes([t['name'] for t in tables],
+			[len(self.primary['ra'])] + [int(t['ra'].shape[0]) for t in tables[1:]], [t['area'] for t in tables], log)
+		comp = nway_amd._completeness_vector(self.prior_completeness, k)
+		self.params = _hip.make_params(k, scheme, self.match_radius, err, dens, dens_plus, nway_amd._prior_table(dens, dens_plus, comp),
+			prob_ratio_secondary=self.prob_ratio_secondary)
+		self.cats = [_hip.DeviceCatalogue(self.primary['ra'], self.primary['dec'], numpy.asarray(self.primary['error'], dtype=float), self.device)]
+		for t in tables[1:]:
+			self.cats.append(_hip.DeviceCatalogue(t['ra'], t['dec'], t['error'], self.device))
+		sizes = [c.n for c in self.cats]
+		cap_pairs, cap_rows = nway_amd._estimate_capacities(sizes, [t['area'] * 1.0 for t in tables], self.match_radius, scheme, True)
+		self.plan, self.status = _hip.run_plan(sizes, self.params, self.cats, cap_pairs, cap_rows, self.device)
+
+	# -- per batch -----------------------------------------------------------------------
+	def step(self):
+		"""one pass of the hot path over this rank's primary shard (no collective)"""
+		if self.compute is not None:
+			tables = self._tables()
+			tables = [dict(t, ra=numpy.asarray(t['ra']), dec=numpy.asarray(t['dec']),
+				error=(t['error'] if numpy.ndim(t['error']) == 0 else numpy.asarray(t['error']))) for t in tables]
+			self.table = self.compute(tables, self.match_radius, self.prior_completeness, prob_ratio_secondary=self.prob_ratio_secondary)
+			return self.table
+		self.plan.enqueue(self.cats)
+
+	def read_status(self):
+		return self.plan.read_status()
+
+	def local_rows(self):
+		if self.compute is not None:
+			return len(self.table['ncat'])
+		from nway_amd import _hip
+		return int(self.plan.read_status()[_hip.ST_ROWS])
+
+	def total_rows(self):
+		"""rows produced by all ranks in one step"""
+		import torch
+		n = self.local_rows()
+		if self.world == 1:
+			return n
+		dev = self.device if self.compute is None else torch.device('cpu')
+		t = torch.tensor([n], dtype=torch.int64, device=dev)
+		_dist().all_reduce(t, group=self.group)
+		return int(t.item())
+
+	def local_table(self):
+		"""this rank's block of the global table as host columns (global primary indices)"""
+		if self.compute is not None:
+			t = dict(self.table)
+		else:
+			from nway_amd import _hip
+			st = self.plan.read_status()
+			m = int(st[_hip.ST_ROWS])
+			names = [self.primary['name']] + [f['name'] for f in self.full_secondaries]
+			t = {}
+			for c, nme in enumerate(names):
+				t[nme] = self.plan.cols['idx'][c][:m].cpu().numpy().astype(numpy.int64)
+			for p, (i, j) in enumerate(_hip.pair_columns(len(names))):
+				t['Separation_%s_%s' % (names[i], names[j])] = self.plan.cols['sep'][p][:m].cpu().numpy()
+			for src, dst in (('sep_max', 'Separation_max'), ('log_bf', 'dist_bayesfactor_uncorrected'), ('log_bf_corrected', 'dist_bayesfactor'),
+					('dist_post', 'dist_post'), ('p_single', 'p_single'), ('p_any', 'prob_has_match'), ('p_i', 'prob_this_match')):
+				t[dst] = self.plan.cols[src][:m].cpu().numpy()
+			t['ncat'] = self.plan.cols['ncat'][:m].cpu().numpy().astype(numpy.int64)
+			t['match_flag'] = self.plan.cols['match_flag'][:m].cpu().numpy().astype(numpy.int64)
+		pname = self.primary['name']
+		t[pname] = numpy.asarray(t[pname]) + self.primary_offset
+		return t
+
+	def gather_table(self, dst=0):
+		"""global table on rank ``dst`` (rank-order concatenation); None elsewhere"""
+		dist = _dist()
+		local = self.local_table()
+		if self.world == 1:
+			return local
+		gathered = [None] * self.world if self.rank == dst else None
+		dist.gather_object(local, gathered, dst=dst, group=self.group)
+		if self.rank != dst:
+			return None
+		out = {}
+		for key in gathered[0]:
+			if key.startswith('_'):
+				continue
+			out[key] = numpy.concatenate([numpy.asarray(g[key]) for g in gathered])
+		return out

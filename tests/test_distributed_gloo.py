@@ -1,0 +1,93 @@
+"""world_size-2 tests of the sharding logic with the gloo backend on CPU.
+
+The HIP kernels cannot run here, so the per-rank compute is the CPU oracle (test
+infrastructure); what is under test is nway_amd.distributed: row sharding of the
+primaries, all-gatherv of uneven secondary slices, global indices and the rank-order
+concatenation reproducing the unsharded table exactly."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from goldenutil import ROOT, cat
+
+sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+
+
+def free_port():
+	s = socket.socket()
+	s.bind(('127.0.0.1', 0))
+	port = s.getsockname()[1]
+	s.close()
+	return port
+
+
+def make_catalogues():
+	rng = np.random.RandomState(21)
+	def patch(n, name, err):
+		return cat(name, rng.uniform(30.0, 30.4, size=n), rng.uniform(-0.2, 0.2, size=n), rng.uniform(0.5 * err, err, size=n), 0.16)
+	return patch(401, 'A', 3.), patch(6001, 'B', 1.), patch(5000, 'C', 2.)
+
+
+def oracle_compute(tables, radius, completeness, **kw):
+	import nway_oracle as orc
+	return orc.nway_match(tables, radius, completeness, prob_ratio_secondary=kw.get('prob_ratio_secondary', 0.5))
+
+
+def worker(rank, world, port, outfile):
+	os.environ['MASTER_ADDR'] = '127.0.0.1'
+	os.environ['MASTER_PORT'] = str(port)
+	dist.init_process_group('gloo', rank=rank, world_size=world)
+	try:
+		from nway_amd import distributed
+		# all-gatherv of uneven (and empty) pieces
+		mine = torch.arange(3 * rank, dtype=torch.float64) + 100 * rank
+		full, counts = distributed.allgatherv(mine)
+		assert counts == [3 * r for r in range(world)]
+		expect = torch.cat([torch.arange(3 * r, dtype=torch.float64) + 100 * r for r in range(world)])
+		assert torch.equal(full, expect)
+
+		A, B, C = make_catalogues()
+		pb = distributed.shard_bounds(len(A['ra']), world)
+		bb = [0, 3500, len(B['ra'])] if world == 2 else distributed.shard_bounds(len(B['ra']), world)
+		cb = [0, 1200, len(C['ra'])] if world == 2 else distributed.shard_bounds(len(C['ra']), world)
+		def rows(t, lo, hi):
+			return dict(t, ra=t['ra'][lo:hi], dec=t['dec'][lo:hi], error=t['error'][lo:hi])
+		sm = distributed.ShardedMatch(rows(A, pb[rank], pb[rank + 1]), [rows(B, bb[rank], bb[rank + 1]), rows(C, cb[rank], cb[rank + 1])],
+			20., 0.85, device=torch.device('cpu'), compute=oracle_compute)
+		assert sm.primary_offset == pb[rank]
+		assert [len(f['ra']) for f in sm.full_secondaries] == [len(B['ra']), len(C['ra'])]
+		sm.step()
+		total = sm.total_rows()
+		table = sm.gather_table(dst=0)
+		if rank == 0:
+			np.savez(outfile, total=total, **table)
+	finally:
+		dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [2])
+def test_sharded_equals_unsharded(tmp_path, world):
+	import nway_oracle as orc
+	outfile = str(tmp_path / 'gathered.npz')
+	mp.spawn(worker, args=(world, free_port(), outfile), nprocs=world, join=True)
+	got = np.load(outfile)
+	A, B, C = make_catalogues()
+	want = orc.nway_match([A, B, C], 20., 0.85)
+	assert int(got['total']) == len(want['ncat']) > 1000
+	for key in want:
+		if key.startswith('_'):
+			continue
+		np.testing.assert_array_equal(got[key], want[key], err_msg=key)
+
+
+def test_shard_bounds():
+	from nway_amd import distributed
+	b = distributed.shard_bounds(10, 4)
+	assert list(b) == [0, 3, 6, 8, 10]
+	assert list(distributed.shard_bounds(2, 4)) == [0, 1, 2, 2, 2]
