@@ -1,0 +1,65 @@
+"""Condense rocprofv3 outputs (kernel_stats.csv, counter_collection.csv of separate FETCH_SIZE /
+WRITE_SIZE passes) into the small text/JSON summaries committed under profiles/.
+
+    python tools/summarize_profile.py gpurun_out/r01 profiles r01 [n_secondary]
+"""
+import csv
+import glob
+import json
+import os
+import sys
+
+src, dst, tag = sys.argv[1], sys.argv[2], sys.argv[3]
+n_secondary = int(sys.argv[4]) if len(sys.argv) > 4 else 10000000
+os.makedirs(dst, exist_ok=True)
+
+
+def short(name):
+	name = name.replace('(anonymous namespace)::', '')
+	return name.split('(')[0].replace('void ', '')
+
+
+lines = []
+stats = glob.glob(os.path.join(src, 'stats', '*', '*kernel_stats.csv'))
+kernel_avg = {}
+if stats:
+	lines.append('# rocprofv3 --kernel-trace --stats -- python bench.py --steps 20 --warmup 3 --cpu-sample 0')
+	lines.append('%-34s %6s %12s %10s %10s %7s' % ('kernel', 'calls', 'total_us', 'avg_us', 'max_us', 'pct'))
+	for r in csv.DictReader(open(stats[0])):
+		nm = short(r['Name'])
+		kernel_avg[nm] = float(r['AverageNs']) / 1e3
+		lines.append('%-34s %6s %12.1f %10.2f %10.2f %7s' % (nm[:34], r['Calls'], float(r['TotalDurationNs']) / 1e3,
+			float(r['AverageNs']) / 1e3, float(r['MaxNs']) / 1e3, r['Percentage']))
+counters = {}
+for which in ('fetch', 'write'):
+	files = glob.glob(os.path.join(src, which, '*', '*counter_collection.csv'))
+	if not files:
+		continue
+	per_kernel = {}
+	for r in csv.DictReader(open(files[0])):
+		per_kernel.setdefault((short(r['Kernel_Name']), r['Counter_Name']), []).append(float(r['Counter_Value']))
+	for (k, c), v in sorted(per_kernel.items()):
+		counters[(k, c)] = sum(v) / len(v)
+if counters:
+	lines.append('')
+	lines.append('# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), mean per dispatch, KiB as reported')
+	for (k, c), v in sorted(counters.items()):
+		if k.startswith('k_'):
+			lines.append('%-34s %-12s %14.1f' % (k[:34], c, v))
+open(os.path.join(dst, 'rocprof_%s.txt' % tag), 'w').write('\n'.join(lines) + '\n')
+print('\n'.join(lines))
+
+# HBM traffic of the sweep per launch, corrected as MI355X_MICROARCH.md prescribes:
+# bytes = KiB * 1024; on gfx950 FETCH_SIZE reports exactly 1/2 of a wide (16 B/lane) coalesced
+# streaming read -> double the fetch side; WRITE_SIZE uncalibrated (tiny here).
+sweep = [k for (k, c) in counters if k.startswith('k_sweep')]
+if sweep:
+	k = sweep[0]
+	fetch = counters.get((k, 'FETCH_SIZE'), 0.0) * 1024 * 2
+	write = counters.get((k, 'WRITE_SIZE'), 0.0) * 1024
+	rec = dict(kernel=k, n_secondary=n_secondary, fetch_size_kib_raw=counters.get((k, 'FETCH_SIZE')),
+		write_size_kib_raw=counters.get((k, 'WRITE_SIZE')), hbm_bytes_per_launch=fetch + write,
+		algorithmic_bytes_per_launch=16.0 * n_secondary, avg_launch_us=kernel_avg.get(k),
+		correction='FETCH_SIZE KiB*1024*2 (gfx950 reports half of a 16 B/lane coalesced stream), WRITE_SIZE KiB*1024')
+	json.dump(rec, open(os.path.join(dst, 'sweep_traffic.json'), 'w'), indent=1)
+	print(json.dumps(rec))
