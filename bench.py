@@ -96,6 +96,8 @@ def main():
 	ap.add_argument('--seed', type=int, default=1)
 	ap.add_argument('--cpu-sample', type=int, default=10000000, help='secondaries in the CPU baseline sample (0 = skip)')
 	ap.add_argument('--profile-stages', action='store_true', help='also time every stage (adds event records to the region)')
+	ap.add_argument('--streams', type=int, default=int(os.environ.get('NWAY_BENCH_STREAMS', '1')),
+		help='independent pipelines (own workspace, own output table, own HIP stream) the steps alternate over')
 	args = ap.parse_args()
 
 	import torch
@@ -149,7 +151,21 @@ def main():
 		cap_pairs, cap_rows = nway_amd._estimate_capacities(sizes, [SKY_AREA, SKY_AREA], args.radius, scheme, True)
 		plan, st = _hip.run_plan(sizes, params, cats, cap_pairs, cap_rows, device)
 		rows_per_step = int(st[_hip.ST_ROWS])
-		step = lambda: plan.enqueue(cats)
+		# every step is a complete, independent pass; with --streams S the steps alternate over S
+		# pipelines (workspace + output table + HIP stream each) so that the latency-bound stages of
+		# one pass overlap the HBM-bound sweep of another
+		plans = [plan] + [_hip.MatchPlan(sizes, params, plan.cap_pairs, plan.cap_rows, device) for _ in range(args.streams - 1)]
+		streams = [torch.cuda.Stream(device=device) for _ in plans] if len(plans) > 1 else [None]
+		counter = [0]
+
+		def step():
+			i = counter[0] % len(plans)
+			counter[0] += 1
+			if streams[i] is None:
+				plans[i].enqueue(cats)
+			else:
+				with torch.cuda.stream(streams[i]):
+					plans[i].enqueue(cats)
 		read_status = plan.read_status
 	else:
 		step = engine.step
@@ -157,6 +173,7 @@ def main():
 		engine.step()
 		rows_per_step = engine.total_rows()
 		plan = engine.plan
+		plans = [plan]
 
 	def barrier():
 		torch.cuda.synchronize(device)
@@ -167,15 +184,20 @@ def main():
 	for _ in range(args.warmup):
 		step()
 	mask = (1 << _hip.STAGES) - 1 if args.profile_stages else (1 << 1)
-	plan.profile(mask)
+	for pl in plans:
+		pl.profile(mask)
 	barrier()
 	t0 = time.perf_counter()
 	for _ in range(args.steps):
 		step()
 	barrier()
 	elapsed = time.perf_counter() - t0
-	launches, ms = plan.profile_read()
-	plan.profile(0)
+	launches, ms = [0] * _hip.STAGES, [0.0] * _hip.STAGES
+	for pl in plans:
+		n_, ms_ = pl.profile_read()
+		launches = [a + b for a, b in zip(launches, n_)]
+		ms = [a + b for a, b in zip(ms, ms_)]
+		pl.profile(0)
 	if world > 1:
 		tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
 		dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -207,7 +229,7 @@ def main():
 				% (args.n_primary, args.n_primary * world, n_sec_swept, args.radius, args.completeness, args.seed),
 				rows_per_step=rows_per_step, distance_tests_per_step_rank0=int(st[_hip.ST_TESTS]),
 				survivors_per_step_rank0=int(st[_hip.ST_SURVIVORS]), registrations_rank0=int(st[_hip.ST_REGISTRATIONS]),
-				parallelism='primary-row shards x%d' % world,
+				parallelism='primary-row shards x%d' % world, streams=len(plans),
 				setup_allgatherv=(None if engine is None else dict(seconds=engine.setup_seconds, bytes=engine.gathered_bytes,
 					note='one-time all-gatherv of the secondary columns (RCCL), outside the timed steps'))),
 			roofline=dict(bound='hbm', kernel='k_sweep', achieved=achieved, peak=HBM_PEAK_GBS, unit='GB/s',
