@@ -158,6 +158,13 @@ int nwayhip_group_stats(int64_t n_rows, int64_t n_groups, const int64_t* group_s
 	const double* prior, double prob_ratio_secondary, double* p_single, double* p_any, double* p_i,
 	int8_t* match_flag, void* stream);
 
+/* Magnitude bias of one column (__init__.py:383-394 with magnitudeweights.fitfunc_histogram
+ * :74-87): row r takes mag[idx[r]] (idx < 0 or undefined magnitude -> weight 0), looks it up in
+ * the step function ratio[bin] over edges[0..n_edges-1] (ratio has n_edges-1 entries),
+ * weight = log10(ratio); total_inout[r] += weight; bias_out[r] = 10^weight. */
+int nwayhip_bias_lookup(int64_t n_rows, const int32_t* idx, const double* mag, int32_t n_edges, const double* edges,
+	const double* ratio, double* total_inout, double* bias_out, void* stream);
+
 /* fastskymatch.py:94-98 on device-resident columns: out[0..3] = min ra, max ra, max |dec|, #NaN */
 int nwayhip_catalogue_extent(const double* ra, const double* dec, int64_t n, double* d_out4, void* stream);
 

@@ -239,7 +239,7 @@ def nway_match(match_tables, match_radius, prior_completeness,
 
 	if has_mags:
 		from . import magpriors
-		table, total = magpriors.apply_magnitude_biasing(match_tables, table, mag_include_radius, mag_exclude_radius,
+		table, total = magpriors.apply_magnitude_biasing(match_tables, table, res, mag_include_radius, mag_exclude_radius,
 			magauto_post_single_minvalue, store_mag_hists, logger=logger)
 		logger.log('')
 		logger.log('Computing final probabilities ...')

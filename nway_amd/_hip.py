@@ -67,6 +67,7 @@ SYMBOLS = {
 	'nwayhip_plan_profile': (ctypes.c_int, [_vp, ctypes.c_uint32]),
 	'nwayhip_plan_profile_read': (ctypes.c_int, [_vp, ctypes.POINTER(_i64), ctypes.POINTER(_dbl)]),
 	'nwayhip_group_stats': (ctypes.c_int, [_i64, _i64, _vp, _vp, _vp, _dbl, _vp, _vp, _vp, _vp, _vp]),
+	'nwayhip_bias_lookup': (ctypes.c_int, [_i64, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp]),
 	'nwayhip_catalogue_extent': (ctypes.c_int, [_vp, _vp, _i64, _vp, _vp]),
 }
 

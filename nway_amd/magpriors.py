@@ -1,0 +1,102 @@
+"""Magnitude (or any other property) priors on top of the distance-based match table.
+
+Restates nwaylib/__init__.py:304-396 (``_apply_magnitude_biasing``): per magnitude column
+build or take the selected/all histograms on the host (catalogue-sized numpy work, once),
+then look every table row up in the resulting step function ON THE DEVICE
+(``nwayhip_bias_lookup``) and run the per-primary statistics with the biased totals
+(``nwayhip_group_stats``, __init__.py:399-461).
+
+The API flavour of the selection logic is reproduced literally, including its indexing of
+the weights by the "defined" rows (``__init__.py:337``; the script uses the selected rows,
+``nway.py:471``) -- outputs must equal ``nwaylib.nway_match``.
+"""
+from __future__ import division, print_function
+
+import numpy
+
+from . import _hip
+from . import magnitudeweights
+
+
+def apply_magnitude_biasing(match_tables, table, res, mag_include_radius, mag_exclude_radius,
+		magauto_post_single_minvalue, store_mag_hists, logger):
+	"""returns (table with bias_* columns, device tensor ``total`` = dist_bayesfactor + sum of log10 biases)"""
+	from . import UndersampledException
+	t = _hip.torch()
+	lib = _hip.load()
+	device = res.plan.device
+	nrows = res.nrows
+	total = res.column('log_bf_corrected').clone()
+	bias_columns = {}
+	for i, tab in enumerate(match_tables):
+		table_name = tab['name']
+		for magvals, maghist, magname in zip(tab['mags'], tab['maghists'], tab['magnames']):
+			col = '%s_%s' % (table_name, magname)
+			mag = '%s:%s' % (table_name, magname)
+			logger.log('Incorporating bias "%s" ...' % mag)
+			res_idx = table[table.columns[i]].values
+			res_defined = res_idx != -1
+			mag_all = magvals
+			mag_all[mag_all == -99] = numpy.nan  # in place, like the reference (:319)
+			mask_all = numpy.isfinite(mag_all)
+			if maghist is None:
+				if mag_include_radius is not None:
+					selection = table['Separation_max'].values < mag_include_radius
+					selection_possible = table['Separation_max'].values < mag_exclude_radius
+					selection_weights = numpy.ones(len(selection))
+				else:
+					selection = (table['dist_post'] > magauto_post_single_minvalue).values
+					selection_weights = table['dist_post'].values
+					selection_possible = (table['dist_post'] > 0.01).values
+				selection = numpy.logical_and(selection, res_defined)
+				selection_weights = selection_weights[res_defined]
+				selection_possible = numpy.logical_and(selection_possible, res_defined)
+				rows, first_seen = numpy.unique(res_idx[selection], return_index=True)
+				rows_weights = selection_weights[first_seen]
+				assert len(rows) > 0, 'No magnitude values within radius for "%s".' % mag
+				mag_sel = magvals[rows]
+				rows_possible = numpy.unique(res_idx[selection_possible])
+				mask_others = mask_all.copy()
+				mask_others[rows_possible] = False
+				mask_sel = ~numpy.logical_or(numpy.isnan(mag_sel), numpy.isinf(mag_sel))
+				logger.log('magnitude histogram of column "%s": %d secure matches, %d insecure matches and %d secure non-matches of %d total entries (%d valid)'
+					% (col, mask_sel.sum(), len(rows_possible), mask_others.sum(), len(mag_all), mask_all.sum()))
+				bins, hist_sel, hist_all = magnitudeweights.adaptive_histograms(mag_all[mask_others], mag_sel[mask_sel],
+					weights=rows_weights[mask_sel])
+				if store_mag_hists:
+					filename = mag.replace(':', '_') + '_fit.txt'
+					logger.log('magnitude histogram stored to "%s".' % filename)
+					with open(filename, 'wb') as f:
+						f.write(b'# lo hi selected others\n')
+						numpy.savetxt(f, numpy.transpose([bins[:-1], bins[1:], hist_sel, hist_all]), fmt=['%10.5f'] * 4)
+				if mask_sel.sum() < 100:
+					raise UndersampledException('ERROR: too few secure matches (%d) to make a good histogram. If you are sure you want to use this poorly sampled histogram, replace "auto" with the filename. You can also decrease the mag-auto-minprob parameter.' % mask_sel.sum())
+			else:
+				logger.log('magnitude histogramming: using user-supplied histogram for "%s"' % (col))
+				bins_lo, bins_hi, hist_sel, hist_all = maghist
+				bins = numpy.array(list(bins_lo) + [bins_hi[-1]])
+			func = magnitudeweights.fitfunc_histogram(bins, hist_sel, hist_all)
+			if store_mag_hists:
+				magnitudeweights.plot_fit(bins, hist_sel, hist_all, func, mag)
+			# per-row lookup on the device: weight = log10(func(mag[idx])), undefined -> 0
+			d_mag = _hip.to_device(numpy.where(numpy.isfinite(mag_all), mag_all, numpy.nan), device)
+			d_edges = _hip.to_device(func.edges, device)
+			d_ratio = _hip.to_device(func.values, device)
+			d_bias = t.empty(nrows, dtype=t.float64, device=device)
+			_hip.check(lib.nwayhip_bias_lookup(nrows, _hip.ptr(res.column('idx', i)), _hip.ptr(d_mag), len(func.edges),
+				_hip.ptr(d_edges), _hip.ptr(d_ratio), _hip.ptr(total), _hip.ptr(d_bias), _hip.current_stream_ptr(device)))
+			bias_columns['bias_%s' % col] = d_bias.cpu().numpy()
+	table = table.assign(**bias_columns)
+	return table, total
+
+
+def final_probabilities_device(res, total, prob_ratio_secondary):
+	"""p_single, p_any, p_i, match_flag from the biased totals (device), as host arrays"""
+	lib = _hip.load()
+	cols = res.plan.cols
+	n_groups = res.plan.sizes[0]
+	_hip.check(lib.nwayhip_group_stats(res.nrows, n_groups, _hip.ptr(cols['group_start']), _hip.ptr(total), _hip.ptr(cols['prior']),
+		prob_ratio_secondary, _hip.ptr(cols['p_single']), _hip.ptr(cols['p_any']), _hip.ptr(cols['p_i']), _hip.ptr(cols['match_flag']),
+		_hip.current_stream_ptr(res.plan.device)))
+	return dict(p_single=res.to_host('p_single'), p_any=res.to_host('p_any'), p_i=res.to_host('p_i'),
+		match_flag=res.to_host('match_flag'))

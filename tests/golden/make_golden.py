@@ -350,3 +350,68 @@ if __name__ == '__main__':
 		gen_ell()
 	if 'xmm' in which:
 		gen_xmm()
+
+
+def gen_mag():
+	"""magnitude priors: XMM x seeded OPT stand-in with a seeded magnitude column in which true
+	counterparts are brighter; auto histograms by radius, by posterior, and a supplied histogram"""
+	XMM = _fits.read_table(os.path.join(REFERENCE, 'doc/COSMOS_XMM.fits'))
+	d = XMM.data
+	rng = np.random.RandomState(77)
+	n_opt = 120000
+	opt_ra = rng.uniform(149.35, 150.87, size=n_opt)
+	opt_dec = rng.uniform(1.47, 2.96, size=n_opt)
+	mag = rng.normal(24.0, 1.5, size=n_opt)
+	# give 1500 XMM sources a bright counterpart close by
+	k = 1500
+	slots = rng.choice(n_opt, size=k, replace=False)
+	opt_ra[slots] = d['RA'][:k] + rng.normal(0, 0.5, size=k) / 3600. / np.cos(np.radians(d['DEC'][:k]))
+	opt_dec[slots] = d['DEC'][:k] + rng.normal(0, 0.5, size=k) / 3600.
+	mag[slots] = rng.normal(21.0, 1.0, size=k)
+	mag[rng.choice(n_opt, size=3000, replace=False)] = -99
+	mag[rng.choice(n_opt, size=500, replace=False)] = np.nan
+	# the catalogue is regenerated from the seed by tests/goldenutil.py:mag_tables (same recipe);
+	# only checksums are stored
+	out = dict(seed=np.array([77]), n_opt=np.array([n_opt]), n_true=np.array([k]),
+		checksum=np.array([opt_ra.sum(), opt_dec.sum(), np.nansum(mag), float(np.isnan(mag).sum())]))
+
+	def tables(maghist):
+		tX = cat('XMM', d['RA'], d['DEC'], d['pos_err'].astype(float), 2.0)
+		tO = cat('OPT', opt_ra, opt_dec, 0.1 * np.ones(n_opt), 2.0)
+		tO['mags'] = [mag.copy()]
+		tO['magnames'] = ['MAG']
+		tO['maghists'] = [maghist]
+		return [tX, tO]
+	cwd = os.getcwd()
+	import tempfile
+	os.chdir(tempfile.mkdtemp(prefix='nwaymag_'))
+	try:
+		for prefix, kw in (('rad_', dict(mag_include_radius=4.0)), ('post_', dict())):
+			res = ref.nway_match(tables(None), match_radius=20., prior_completeness=0.9, store_mag_hists=False, logger=LOG, **kw)
+			out.update(table_arrays(res, ['XMM', 'OPT'], prefix))
+			out[prefix + 'bias'] = res['bias_OPT_MAG'].values
+		# histogram file written by the reference + the run that consumes it
+		res = ref.nway_match(tables(None), match_radius=20., prior_completeness=0.9, store_mag_hists=True, mag_include_radius=4.0, logger=LOG)
+		out['hist_text'] = np.frombuffer(open('OPT_MAG_fit.txt', 'rb').read(), dtype=np.uint8)
+		lo, hi, hs, ha = np.loadtxt('OPT_MAG_fit.txt').transpose()
+		res = ref.nway_match(tables((lo, hi, hs, ha)), match_radius=20., prior_completeness=0.9, store_mag_hists=False, logger=LOG)
+		out.update(table_arrays(res, ['XMM', 'OPT'], 'file_'))
+		out['file_bias'] = res['bias_OPT_MAG'].values
+	finally:
+		os.chdir(cwd)
+	# the interpolants the reference builds with scipy, on fixed inputs
+	mw = ref.magnitudeweights
+	a = rng.normal(22, 2, size=4000)
+	s = rng.normal(20, 1, size=300)
+	w = rng.uniform(0.2, 1, size=300)
+	bins, hs, ha = mw.adaptive_histograms(a, s, weights=w)
+	out['ah_all'], out['ah_sel'], out['ah_w'] = a, s, w
+	out['ah_bins'], out['ah_hist_sel'], out['ah_hist_all'] = bins, hs, ha
+	x = np.r_[np.linspace(bins[0] - 1, bins[-1] + 1, 501), bins, np.nan]
+	out['ff_x'] = x
+	out['ff_y'] = mw.fitfunc_histogram(bins, hs, ha)(x)
+	save('mag', **out)
+
+
+if __name__ == '__main__' and ('mag' in sys.argv[1:] or not sys.argv[1:]):
+	gen_mag()

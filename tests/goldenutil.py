@@ -48,6 +48,30 @@ def xmm_tables():
 	return X, O, I
 
 
+def mag_tables(maghist=None):
+	"""XMM x seeded OPT stand-in with a magnitude column (recipe of make_golden.py:gen_mag)"""
+	g = golden('xmm_inputs')
+	m = golden('mag')
+	rng = np.random.RandomState(int(m['seed'][0]))
+	n_opt, k = int(m['n_opt'][0]), int(m['n_true'][0])
+	opt_ra = rng.uniform(149.35, 150.87, size=n_opt)
+	opt_dec = rng.uniform(1.47, 2.96, size=n_opt)
+	mag = rng.normal(24.0, 1.5, size=n_opt)
+	slots = rng.choice(n_opt, size=k, replace=False)
+	opt_ra[slots] = g['RA'][:k] + rng.normal(0, 0.5, size=k) / 3600. / np.cos(np.radians(g['DEC'][:k]))
+	opt_dec[slots] = g['DEC'][:k] + rng.normal(0, 0.5, size=k) / 3600.
+	mag[slots] = rng.normal(21.0, 1.0, size=k)
+	mag[rng.choice(n_opt, size=3000, replace=False)] = -99
+	mag[rng.choice(n_opt, size=500, replace=False)] = np.nan
+	np.testing.assert_allclose([opt_ra.sum(), opt_dec.sum(), np.nansum(mag), float(np.isnan(mag).sum())], m['checksum'], rtol=0, atol=0)
+	X = cat('XMM', g['RA'], g['DEC'], g['pos_err'].astype(float), 2.0)
+	O = cat('OPT', opt_ra, opt_dec, 0.1 * np.ones(n_opt), 2.0)
+	O['mags'] = [mag]
+	O['magnames'] = ['MAG']
+	O['maghists'] = [maghist]
+	return [X, O]
+
+
 def idx_hash(idx):
 	idx = np.asarray(idx).astype(np.int64)
 	w = np.arange(1, len(idx) + 1, dtype=np.uint64)

@@ -10,7 +10,7 @@ import sys
 import numpy as np
 import pytest
 
-from goldenutil import (ROOT, golden, ell_tables, xmm_tables, assert_table_matches,
+from goldenutil import (ROOT, golden, ell_tables, xmm_tables, mag_tables, assert_table_matches,
 	assert_checksums_match, idx_hash, cat, RTOL, ATOL)
 
 sys.path.insert(0, os.path.join(ROOT, 'oracle'))
@@ -141,6 +141,29 @@ def test_edge_cases_golden(nw):
 	tabs = [cat('T%d' % i, g['k4_ra%d' % i], g['k4_dec%d' % i], g['k4_err%d' % i], g['k4_area'][0]) for i in range(4)]
 	t = run(nw, tabs, float(g['k4_radius'][0]), float(g['k4_completeness'][0]))
 	assert_table_matches(t, g, 'k4_', ['T0', 'T1', 'T2', 'T3'])
+
+
+def test_magnitude_priors_golden(nw, tmp_path, monkeypatch):
+	"""__init__.py:304-396: auto histogram by radius, by posterior, user-supplied histogram"""
+	g = golden('mag')
+	monkeypatch.chdir(tmp_path)
+	for prefix, kw in (('rad_', dict(mag_include_radius=4.0)), ('post_', dict())):
+		t = run(nw, mag_tables(), 20., 0.9, store_mag_hists=False, **kw)
+		assert_table_matches(t, g, prefix, ['XMM', 'OPT'])
+		np.testing.assert_allclose(t['bias_OPT_MAG'], g[prefix + 'bias'], rtol=RTOL)
+	# the histogram file has the reference's format, and feeding it back reproduces its run
+	run(nw, mag_tables(), 20., 0.9, store_mag_hists=True, mag_include_radius=4.0)
+	text = open('OPT_MAG_fit.txt', 'rb').read()
+	assert text == g['hist_text'].tobytes()
+	lo, hi, hs, ha = np.loadtxt('OPT_MAG_fit.txt').transpose()
+	t = run(nw, mag_tables((lo, hi, hs, ha)), 20., 0.9, store_mag_hists=False)
+	assert_table_matches(t, g, 'file_', ['XMM', 'OPT'])
+	np.testing.assert_allclose(t['bias_OPT_MAG'], g['file_bias'], rtol=RTOL)
+	# too few secure matches -> the reference's exception type
+	few = mag_tables()
+	few[0] = dict(few[0], ra=few[0]['ra'][:30], dec=few[0]['dec'][:30], error=few[0]['error'][:30])
+	with pytest.raises(nw.UndersampledException):
+		run(nw, few, 20., 0.9, store_mag_hists=False, mag_include_radius=4.0)
 
 
 def test_empty_secondary_catalogue(nw):
