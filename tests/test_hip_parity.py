@@ -227,3 +227,47 @@ def test_flat_scheme_random_vs_oracle(nw):
 	a, b, c, d = patch(800, 'A', 3.), patch(30000, 'B', 1.), patch(25000, 'C', 2.), patch(10000, 'D', 1.5)
 	oracle_vs_hip(nw, [a, b], 25., 0.9, ['A', 'B'])
 	oracle_vs_hip(nw, [a, b, c, d], 25., np.array([1.0, 0.9, 0.8, 0.7]), ['A', 'B', 'C', 'D'], correction='cli')
+
+
+def test_cli_fits_in_fits_out(nw, tmp_path, monkeypatch):
+	"""nway.py surface: FITS catalogues in, FITS table out (columns, order and formats of
+	SURVEY.md appendix C); values = the API's, stored as float32"""
+	from nway_amd import _fits, cli
+	monkeypatch.chdir(tmp_path)
+	X, R, O = ell_tables()
+	for t, extra in ((X, 'pos_err'), (R, 'pos_err'), (O, None)):
+		n = len(t['ra'])
+		cols = [('ID', 'J', np.arange(1, n + 1)), ('RA', 'D', t['ra']), ('DEC', 'D', t['dec'])]
+		if extra:
+			cols.append((extra, 'D', t['error']))
+		_fits.write_table('%s.fits' % t['name'], cols, t['name'], table_header={'SKYAREA': t['area']})
+	assert cli.main(['--radius', '10', 'CHANDRA.fits', ':pos_err', 'OPT.fits', '0.1', '--out=out2.fits', '--prior-completeness', '0.9']) == 0
+	out = _fits.read_table('out2.fits')
+	assert out.name == 'NWAYMATCH'
+	assert out.names == ['CHANDRA_ID', 'CHANDRA_RA', 'CHANDRA_DEC', 'CHANDRA_pos_err', 'OPT_ID', 'OPT_RA', 'OPT_DEC',
+		'Separation_OPT_CHANDRA', 'Separation_max', 'ncat', 'dist_bayesfactor', 'dist_post', 'p_single', 'p_any', 'p_i', 'match_flag']
+	assert out.formats[7:] == ['E', 'E', 'I', 'E', 'E', 'E', 'E', 'E', 'I']
+	api = run(nw, [X, O], 10., 0.9)
+	assert len(out.data) == len(api['ncat']) == 37706
+	np.testing.assert_array_equal(out.data['CHANDRA_ID'], api['CHANDRA'] + 1)
+	np.testing.assert_array_equal(out.data['OPT_ID'], np.where(api['OPT'] >= 0, api['OPT'] + 1, -99))
+	np.testing.assert_array_equal(out.data['match_flag'], api['match_flag'])
+	np.testing.assert_array_equal(out.data['OPT_RA'][api['OPT'] < 0], -99)
+	for a, b in (('p_any', 'prob_has_match'), ('p_i', 'prob_this_match'), ('dist_bayesfactor', 'dist_bayesfactor'), ('dist_post', 'dist_post'),
+			('Separation_max', 'Separation_max')):
+		np.testing.assert_array_equal(out.data[a], api[b].astype(np.float32), err_msg=a)
+	# three catalogues: corrected Bayes factors appear, --min-prob trims
+	assert cli.main(['--radius', '10', 'CHANDRA.fits', ':pos_err', 'XMM.fits', ':pos_err', 'OPT.fits', '0.1', '--out', 'out3.fits', '--min-prob', '0.01']) == 0
+	out3 = _fits.read_table('out3.fits')
+	assert 'dist_bayesfactor_corrected' in out3.names and 'Separation_OPT_XMM' in out3.names
+	api3 = run(nw, [X, R, O], 10., 1.0, unrelated_associations='cli', min_prob=0.01)
+	assert len(out3.data) == len(api3['ncat'])
+	np.testing.assert_array_equal(out3.data['dist_bayesfactor_corrected'], api3['dist_bayesfactor'].astype(np.float32))
+	np.testing.assert_array_equal(out3.data['match_flag'], api3['match_flag'])
+
+
+def test_nwaylib_alias(nw):
+	import nwaylib
+	import nwaylib.bayesdistance as bd
+	assert nwaylib.nway_match is nw.nway_match and nwaylib.__version__ == '4.7.1'
+	assert bd.log_bf2(0.3, 0.1, 0.2) == pytest.approx(11.840045223967955, rel=1e-14)
