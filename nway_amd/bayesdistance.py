@@ -93,3 +93,117 @@ def log_bf(p, s):
 	out = t.empty(nrows, dtype=t.float64, device=device)
 	_hip.check(_hip.load().nwayhip_log_bf(n, nrows, sep, sig, _hip.ptr(out), _hip.current_stream_ptr(device)))
 	return _finish(out, shape)
+
+
+# ---------------------------------------------------------------------------------------
+# Elliptical / asymmetric position errors (reference: bayesdistance.py:92-240).
+# Host-side numpy helpers on 2x2 matrices whose entries are arrays ("vectorised": one
+# matrix per table row).  They reduce an elliptical error to the circular formula by
+# rescaling each separation with the error along its direction; the Bayes factor itself is
+# again ``log_bf`` on the device.
+# ---------------------------------------------------------------------------------------
+
+def assert_possemdef(M):
+	"""raise AssertionError unless the symmetric 2x2 matrix M (entries may be arrays) is
+	positive semi-definite"""
+	(a, b), (_, d) = M
+	tr = a + d
+	det = a * d - b * b
+	degenerate = numpy.isclose(tr**2, 4 * det)
+	if numpy.all(degenerate):
+		return
+	disc = tr**2 - 4 * det
+	assert not numpy.any(numpy.logical_and(~degenerate, disc < 0)), (tr, det, M)
+	root = numpy.sqrt(numpy.where(degenerate, 0, disc))
+	for ev in ((tr + root) / 2, (tr - root) / 2):
+		assert numpy.all(numpy.where(degenerate, 0, ev) >= 0), ('negative eigenvalue', ev, M)
+
+
+def matrix_add(A, B):
+	return tuple(tuple(x + y for x, y in zip(ra, rb)) for ra, rb in zip(A, B))
+
+
+def matrix_multiply(A, B):
+	(a, b), (c, d) = A
+	(e, f), (g, h) = B
+	return (a * e + b * g, a * f + b * h), (c * e + d * g, c * f + d * h)
+
+
+def matrix_det(A):
+	(a, b), (c, d) = A
+	return a * d - b * c
+
+
+def matrix_invert(A):
+	(a, b), (c, d) = A
+	scale = 1.0 / matrix_det(A)
+	assert numpy.all(scale > 0)
+	return (scale * d, -scale * b), (-scale * c, scale * a)
+
+
+def apply_vector_right(A, b):
+	"""A b"""
+	(a11, a12), (a21, a22) = A
+	return a11 * b[0] + a12 * b[1], a21 * b[0] + a22 * b[1]
+
+
+def apply_vector_left(a, B):
+	"""a^T B"""
+	(b11, b12), (b21, b22) = B
+	return a[0] * b11 + a[1] * b21, a[0] * b12 + a[1] * b22
+
+
+def vector_multiply(a, b):
+	return a[0] * b[0] + a[1] * b[1]
+
+
+def vector_normalised(v):
+	"""unit vector along v; (1, 1)/sqrt(2) where v vanishes"""
+	length = (v[0]**2 + v[1]**2)**0.5
+	return tuple(numpy.where(length == 0, 2**-0.5, comp / (length + 1e-300)) for comp in v)
+
+
+def apply_vABv(v, A, B):
+	"""v^T (A + B) v"""
+	return vector_multiply(v, apply_vector_right(matrix_add(A, B), v))
+
+
+def make_covmatrix(sigma_x, sigma_y, rho=0):
+	off = rho * sigma_x * sigma_y
+	return (sigma_x**2, off), (off, sigma_y**2)
+
+
+def make_invcovmatrix(sigma_x, sigma_y, rho=0):
+	scale = 1.0 / (sigma_x**2 * sigma_y**2 * (1 - rho**2))
+	off = scale * -rho * sigma_x * sigma_y
+	return (scale * sigma_y**2, off), (off, scale * sigma_x**2)
+
+
+def convert_from_ellipse(a, b, phi):
+	"""(sigma_x, sigma_y, rho) of an error ellipse with semi-axes a, b rotated by phi
+	(radians), e.g. Pineau+16 eq. 8-10"""
+	s2, c2 = numpy.sin(phi)**2, numpy.cos(phi)**2
+	sigma_x = (a**2 * s2 + b**2 * c2)**0.5
+	sigma_y = (a**2 * c2 + b**2 * s2)**0.5
+	rho = numpy.cos(phi) * numpy.sin(phi) * (a**2 - b**2) / (sigma_x * sigma_y)
+	return sigma_x, sigma_y, rho
+
+
+def log_bf_elliptical(separations_ra, separations_dec, pos_errors):
+	"""log10 Bayes factor for elliptical errors: pos_errors = list of (sigma_ra, sigma_dec, rho)
+	per catalogue; separations given per axis.  Each pair's separation is rescaled by the
+	ratio of the circularised to the directional error, then the circular formula applies."""
+	inverse = [make_invcovmatrix(sx, sy, rho) for sx, sy, rho in pos_errors]
+	circular = [((sx**2 + sy**2) / 2)**0.5 for sx, sy, rho in pos_errors]
+	n = len(inverse)
+	rescaled = [[None] * n for _ in range(n)]
+	for i in range(n):
+		for j in range(i + 1, n):
+			v = (separations_ra[i][j], separations_dec[i][j])
+			length = vector_multiply(v, v)**0.5
+			unit = vector_normalised(v)
+			wi = vector_multiply(apply_vector_left(unit, inverse[i]), unit)
+			wj = vector_multiply(apply_vector_left(unit, inverse[j]), unit)
+			stretch = (circular[i]**2 + circular[j]**2) / (1 / wi + 1 / wj)
+			rescaled[i][j] = length * stretch**-0.5
+	return log_bf(rescaled, circular)

@@ -413,5 +413,40 @@ def gen_mag():
 	save('mag', **out)
 
 
+def gen_ellmath():
+	"""elliptical-error helpers of bayesdistance.py:92-240 on seeded inputs"""
+	bd = ref.bayesdist
+	rng = np.random.RandomState(5)
+	n = 300
+	a, b = rng.uniform(0.1, 5, size=n), rng.uniform(0.1, 5, size=n)
+	phi = rng.uniform(0, np.pi, size=n)
+	sx, sy, rho = bd.convert_from_ellipse(a, b, phi)
+	out = dict(a=a, b=b, phi=phi, sigma_x=sx, sigma_y=sy, rho=rho)
+	inv = bd.make_invcovmatrix(sx, sy, rho)
+	cov = bd.make_covmatrix(sx, sy, rho)
+	out['inv'] = np.array(inv)
+	out['cov'] = np.array(cov)
+	v = rng.normal(0, 1, size=(2, n))
+	a2, b2, phi2 = rng.uniform(0.1, 5, size=n), rng.uniform(0.1, 5, size=n), rng.uniform(0, np.pi, size=n)
+	e2 = bd.convert_from_ellipse(a2, b2, phi2)
+	out['v'] = v
+	out['a2'], out['b2'], out['phi2'] = a2, b2, phi2
+	out['vABv'] = bd.apply_vABv(v, inv, bd.make_invcovmatrix(*e2))
+	a3, b3, phi3 = rng.uniform(0.1, 5, size=n), rng.uniform(0.1, 5, size=n), rng.uniform(0, np.pi, size=n)
+	e3 = bd.convert_from_ellipse(a3, b3, phi3)
+	out['a3'], out['b3'], out['phi3'] = a3, b3, phi3
+	dra = rng.normal(0, 2, size=(3, n))
+	ddec = rng.normal(0, 2, size=(3, n))
+	out['dra'], out['ddec'] = dra, ddec
+	nan = np.nan * np.ones(n)
+	sra = [[nan, dra[0], dra[1]], [nan, nan, dra[2]], [nan, nan, nan]]
+	sdec = [[nan, ddec[0], ddec[1]], [nan, nan, ddec[2]], [nan, nan, nan]]
+	out['log_bf_ell3'] = bd.log_bf_elliptical(sra, sdec, [(sx, sy, rho), e2, e3])
+	out['log_bf_ell2'] = bd.log_bf_elliptical([[nan, dra[0]], [nan, nan]], [[nan, ddec[0]], [nan, nan]], [(sx, sy, rho), e2])
+	save('ellmath', **out)
+
+
 if __name__ == '__main__' and ('mag' in sys.argv[1:] or not sys.argv[1:]):
 	gen_mag()
+if __name__ == '__main__' and ('ellmath' in sys.argv[1:] or not sys.argv[1:]):
+	gen_ellmath()

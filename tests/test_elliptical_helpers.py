@@ -1,0 +1,74 @@
+"""elliptical-error helpers of nway_amd.bayesdistance (host numpy) against values computed
+by the reference (tests/golden/ellmath.npz) and the limits its own tests check
+(tests/bayesdistance_test.py:34-145 of the reference)."""
+import numpy as np
+import pytest
+
+from goldenutil import golden
+
+
+def test_convert_and_matrices_match_reference():
+	from nway_amd import bayesdistance as bd
+	g = golden('ellmath')
+	sx, sy, rho = bd.convert_from_ellipse(g['a'], g['b'], g['phi'])
+	np.testing.assert_allclose(sx, g['sigma_x'], rtol=1e-14)
+	np.testing.assert_allclose(sy, g['sigma_y'], rtol=1e-14)
+	np.testing.assert_allclose(rho, g['rho'], rtol=1e-12, atol=1e-15)
+	np.testing.assert_allclose(np.array(bd.make_invcovmatrix(sx, sy, rho)), g['inv'], rtol=1e-12)
+	np.testing.assert_allclose(np.array(bd.make_covmatrix(sx, sy, rho)), g['cov'], rtol=1e-12)
+	e2 = bd.convert_from_ellipse(g['a2'], g['b2'], g['phi2'])
+	got = bd.apply_vABv(g['v'], bd.make_invcovmatrix(sx, sy, rho), bd.make_invcovmatrix(*e2))
+	np.testing.assert_allclose(got, g['vABv'], rtol=1e-12)
+	assert (got >= 0).all()
+	bd.assert_possemdef(bd.make_invcovmatrix(sx, sy, rho))
+	bd.assert_possemdef(bd.matrix_add(bd.make_invcovmatrix(sx, sy, rho), bd.make_invcovmatrix(*e2)))
+	with pytest.raises(AssertionError):
+		bd.assert_possemdef(((np.array([1.0]), np.array([3.0])), (np.array([3.0]), np.array([1.0]))))
+
+
+def test_ellipse_limits():
+	from nway_amd import bayesdistance as bd
+	rng = np.random.RandomState(1)
+	s1, s2, ang = rng.uniform(1, 100, 100), rng.uniform(1, 100, 100), rng.uniform(0, 180, 100)
+	sx, sy, rho = bd.convert_from_ellipse(s1, s1, ang)  # circular
+	np.testing.assert_allclose(rho, 0, atol=1e-12)
+	np.testing.assert_allclose(sx, s1)
+	np.testing.assert_allclose(sy, s1)
+	sx, sy, rho = bd.convert_from_ellipse(s1, s2, 0)  # aligned
+	np.testing.assert_allclose(rho, 0, atol=1e-12)
+	np.testing.assert_allclose(sy, s1)
+	np.testing.assert_allclose(sx, s2)
+	sx, sy, rho = bd.convert_from_ellipse(s1, s2, np.pi / 2)  # rotated by 90 degrees
+	np.testing.assert_allclose(sx, s1)
+	np.testing.assert_allclose(sy, s2)
+	# inverse really inverts, determinant multiplies
+	A = bd.make_covmatrix(s1, s2, 0.3)
+	I = bd.matrix_multiply(A, bd.matrix_invert(A))
+	np.testing.assert_allclose(I[0][0], 1)
+	np.testing.assert_allclose(I[0][1], 0, atol=1e-9)
+	np.testing.assert_allclose(bd.matrix_det(bd.make_invcovmatrix(s1, s2, 0.3)), 1 / bd.matrix_det(A), rtol=1e-10)
+	u = bd.vector_normalised((np.array([3.0, 0.0]), np.array([4.0, 0.0])))
+	np.testing.assert_allclose(u[0], [0.6, 2**-0.5])
+	np.testing.assert_allclose(bd.apply_vector_left((1.0, 2.0), ((1.0, 2.0), (3.0, 4.0))), (7.0, 10.0))
+	np.testing.assert_allclose(bd.apply_vector_right(((1.0, 2.0), (3.0, 4.0)), (1.0, 2.0)), (5.0, 11.0))
+
+
+@pytest.mark.gpu
+def test_log_bf_elliptical_gpu():
+	from nway_amd import bayesdistance as bd
+	g = golden('ellmath')
+	n = len(g['a'])
+	nan = np.nan * np.ones(n)
+	e1 = bd.convert_from_ellipse(g['a'], g['b'], g['phi'])
+	e2 = bd.convert_from_ellipse(g['a2'], g['b2'], g['phi2'])
+	e3 = bd.convert_from_ellipse(g['a3'], g['b3'], g['phi3'])
+	dra, ddec = g['dra'], g['ddec']
+	got = bd.log_bf_elliptical([[nan, dra[0], dra[1]], [nan, nan, dra[2]], [nan, nan, nan]],
+		[[nan, ddec[0], ddec[1]], [nan, nan, ddec[2]], [nan, nan, nan]], [e1, e2, e3])
+	np.testing.assert_allclose(got, g['log_bf_ell3'], rtol=1e-9)
+	got = bd.log_bf_elliptical([[nan, dra[0]], [nan, nan]], [[nan, ddec[0]], [nan, nan]], [e1, e2])
+	np.testing.assert_allclose(got, g['log_bf_ell2'], rtol=1e-9)
+	# elliptical reduces to circular (tests/bayesdistance_test.py:149-203 of the reference)
+	one = np.ones(1)
+	ell = bd.log_bf_elliptical([[None, one]], [[None, 0 * one]], [bd.convert_from_ellipse(0.1 * one, 0.1 * one, 0), bd.convert_from_ellipse(0.2 * one, 0.2 * one, 0)])
+	np.testing.assert_allclose(ell, bd.log_bf([[None, one]], [0.1 * one, 0.2 * one]), rtol=1e-9)
