@@ -1,5 +1,13 @@
-"""print the status words and per-stage timings of one bench-workload run (GPU)"""
-import os, sys
+"""Per-stage timings and status words of one workload on the GPU (development aid).
+
+    python tools/status_probe.py [c3s|c3d|c4s|c4d] [n_primary] [n_secondary] [radius]
+
+c3s: 2-way uniform sky (bench workload)      c3d: 2-way dense 6 deg^2 patch (flat cells)
+c4s: 3-way uniform sky, 1e5 x 1e6 x 1e6     c4d: 3-way dense 8 deg^2 patch
+"""
+import os
+import sys
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
@@ -7,24 +15,74 @@ import torch
 import bench
 import nway_amd
 from nway_amd import _hip
-n0 = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
-n1 = int(sys.argv[2]) if len(sys.argv) > 2 else 10000000
-radius = float(sys.argv[3]) if len(sys.argv) > 3 else 5.0
-prim, sec = bench.make_workload(n0, n1, 1)
-tables = [prim, sec]
+
+args = sys.argv[1:]
+config = args.pop(0) if args and not args[0].isdigit() else 'c3s'
+n0 = int(args[0]) if len(args) > 0 else 100000
+n1 = int(args[1]) if len(args) > 1 else (10000000 if config.startswith('c3') else 1000000)
+radius = float(args[2]) if len(args) > 2 else (5.0 if config.startswith('c3') else 10.0)
+rng = np.random.default_rng(3)
+
+
+def patch_catalogue(name, n, half, sigma, parents=None, frac=0.0, psig=None):
+	ra = rng.uniform(150 - half, 150 + half, size=n)
+	dec = rng.uniform(2 - half, 2 + half, size=n)
+	if parents is not None:
+		m = int(frac * len(parents['ra']))
+		slots = rng.choice(n, size=m, replace=False)
+		dec[slots] = parents['dec'][:m] + rng.normal(0, 1, size=m) * psig[:m] / 3600.
+		ra[slots] = parents['ra'][:m] + rng.normal(0, 1, size=m) * psig[:m] / 3600. / np.cos(np.radians(parents['dec'][:m]))
+	return dict(name=name, ra=ra, dec=dec, error=sigma, area=(2 * half)**2, mags=[], maghists=[], magnames=[])
+
+
+def sphere_catalogue(name, n, sigma, parents=None, frac=0.0, psig=None):
+	ra, dec = bench.uniform_sphere(rng, n)
+	if parents is not None:
+		m = int(frac * len(parents['ra']))
+		slots = rng.choice(n, size=m, replace=False)
+		dec[slots] = np.clip(parents['dec'][:m] + rng.normal(0, 1, size=m) * psig[:m] / 3600., -90, 90)
+		ra[slots] = (parents['ra'][:m] + rng.normal(0, 1, size=m) * psig[:m] / 3600. / np.maximum(np.cos(np.radians(parents['dec'][:m])), 1e-6)) % 360
+	return dict(name=name, ra=ra, dec=dec, error=sigma, area=bench.SKY_AREA, mags=[], maghists=[], magnames=[])
+
+
+if config == 'c3s':
+	prim, sec = bench.make_workload(n0, n1, 1)
+	tables = [prim, sec]
+elif config == 'c3d':
+	psig = rng.uniform(0.3, 1.5, size=n0)
+	prim = patch_catalogue('P', n0, 1.23, psig)
+	tables = [prim, patch_catalogue('S', n1, 1.23, 0.1, prim, 0.8, psig)]
+elif config == 'c4s':
+	psig = np.ones(n0)
+	prim = sphere_catalogue('P', n0, psig)
+	tables = [prim, sphere_catalogue('A', n1, 0.1, prim, 0.8, psig), sphere_catalogue('B', n1, 0.5, prim, 0.6, psig)]
+elif config == 'c4d':
+	psig = np.ones(n0)
+	prim = patch_catalogue('P', n0, 1.42, psig)
+	tables = [prim, patch_catalogue('A', n1, 1.42, 0.1, prim, 0.8, psig), patch_catalogue('B', n1, 1.42, 0.5, prim, 0.6, psig)]
+else:
+	raise SystemExit('unknown config ' + config)
+
+k = len(tables)
 dev = torch.device('cuda', 0)
 log = nway_amd.NullOutputLogger()
 err = radius / 3600.
 scheme = nway_amd.choose_scheme([(t['ra'], t['dec']) for t in tables], err)
 dens, dp = nway_amd._compute_source_densities(tables, log)
-comp = nway_amd._completeness_vector(0.9, 2)
-params = _hip.make_params(2, scheme, radius, err, dens, dp, nway_amd._prior_table(dens, dp, comp))
+comp = nway_amd._completeness_vector(0.9, k)
+params = _hip.make_params(k, scheme, radius, err, dens, dp, nway_amd._prior_table(dens, dp, comp))
 cats = [_hip.DeviceCatalogue(t['ra'], t['dec'], np.asarray(t['error'], dtype=float), dev) for t in tables]
-plan, st = _hip.run_plan([c.n for c in cats], params, cats, 500000, 500000, dev)
-print('status', [int(x) for x in st[:4]], 'surv', int(st[8]), 'pairs', int(st[16]), 'notflat', [int(x) for x in st[24:26]])
+sizes = [c.n for c in cats]
+cap_pairs, cap_rows = nway_amd._estimate_capacities(sizes, [t['area'] for t in tables], radius, scheme, True)
+plan, st = _hip.run_plan(sizes, params, cats, cap_pairs, cap_rows, dev)
+print(config, 'scheme', scheme, 'status', [int(x) for x in st[:4]], 'surv', [int(x) for x in st[8:8 + k - 1]],
+	'pairs', [int(x) for x in st[16:16 + k - 1]], 'notflat', [int(x) for x in st[24:24 + k]])
 plan.profile(0xff)
-for _ in range(10):
+reps = 10
+for _ in range(reps):
 	plan.enqueue(cats)
 torch.cuda.synchronize()
 n, ms = plan.profile_read()
-print('stages us:', ' '.join('%s=%.1f' % (nm, 1e3 * m / max(k, 1)) for nm, k, m in zip(_hip.STAGE_NAMES, n, ms)))
+stage_us = [1e3 * m / reps for m in ms]
+print('stages us/step:', ' '.join('%s=%.1f' % (nm, v) for nm, v in zip(_hip.STAGE_NAMES, stage_us)),
+	'| total=%.1f us  rows/s=%.3g' % (sum(stage_us), int(st[0]) / (sum(stage_us) * 1e-6)))
