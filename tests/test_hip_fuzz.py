@@ -1,0 +1,104 @@
+"""Randomised GPU parity: many small seeded configurations (2..5 catalogues, flat-cell and
+all-sky inputs, clusters on the poles / RA seam / cell borders, duplicates, tiny and huge
+radii, scalar and per-source errors) against the numpy oracle."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from goldenutil import ROOT, RTOL, ATOL, cat
+
+sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+import nway_oracle as orc  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+FLOATS = ('Separation_max', 'dist_bayesfactor_uncorrected', 'dist_bayesfactor', 'dist_post', 'p_single', 'prob_has_match', 'prob_this_match')
+
+
+def compare(nw, tabs, radius, completeness, correction):
+	names = [t['name'] for t in tabs]
+	want = orc.nway_match(tabs, radius, completeness, correction=correction, literal_groups=True)
+	got = nw.nway_match(tabs, radius, completeness, logger=nw.NullOutputLogger(),
+		unrelated_associations='cli' if correction == 'cli' else 'api')
+	assert len(got) == len(want['ncat']), (len(got), len(want['ncat']))
+	for n in names:
+		np.testing.assert_array_equal(got[n].values, want[n])
+	np.testing.assert_array_equal(got['ncat'].values, want['ncat'])
+	k = len(names)
+	for i in range(k):
+		for j in range(i + 1, k):
+			c = 'Separation_%s_%s' % (names[i], names[j])
+			np.testing.assert_allclose(got[c].values, want[c], rtol=RTOL, atol=1e-9, equal_nan=True)
+	for c in FLOATS:
+		np.testing.assert_allclose(got[c].values, want[c], rtol=RTOL, atol=ATOL, err_msg=c)
+	# flags: identical unless two p_i of one primary are equal to within rounding (documented)
+	if not (got['match_flag'].values == want['match_flag']).all():
+		bad = np.flatnonzero(got['match_flag'].values != want['match_flag'])
+		prim = want[names[0]]
+		for r in bad:
+			same = prim == prim[r]
+			pi = np.sort(want['prob_this_match'][same])
+			best = pi[-1]
+			near_tie = np.isclose(pi, best, rtol=1e-12).sum() > 1 or np.isclose(pi, 0.5 * best, rtol=1e-12).any()
+			assert near_tie, 'match_flag differs without a rounding-level tie (row %d)' % r
+	return len(got)
+
+
+def flat_case(rng, k):
+	dec0 = rng.choice([-30.0, -0.02, 0.0, 0.03, 20.0, 44.0])
+	ra0 = rng.uniform(5, 350)
+	radius = float(rng.choice([3.0, 10.0, 30.0, 120.0]))
+	span = radius / 3600. * rng.uniform(6, 40)
+	tabs = []
+	for c in range(k):
+		n = int(rng.integers(1, 40 if c == 0 else 400))
+		ra = ra0 + rng.uniform(0, span, size=n)
+		dec = dec0 + rng.uniform(-span / 2, span / 2, size=n)
+		if c > 0 and n > 4 and rng.random() < 0.5:  # duplicates and exact cell-border positions
+			ra[1] = ra[0]; dec[1] = dec[0]
+			ra[2] = np.round(ra[2] / (radius / 3600.)) * (radius / 3600.)
+		err = rng.uniform(0.2, radius / 3, size=n)
+		tabs.append(cat('T%d' % c, ra, np.clip(dec, -44.9, 44.9), err, max(span * span, 1e-6)))
+	if k > 1 and rng.random() < 0.7:  # true counterparts
+		m = min(len(tabs[0]['ra']), len(tabs[1]['ra']))
+		tabs[1]['ra'][:m] = tabs[0]['ra'][:m] + rng.normal(0, radius / 5, size=m) / 3600.
+		tabs[1]['dec'][:m] = np.clip(tabs[0]['dec'][:m] + rng.normal(0, radius / 5, size=m) / 3600., -44.9, 44.9)
+	return tabs, radius
+
+
+def sphere_case(rng, k):
+	radius = float(rng.choice([20.0, 200.0, 2000.0]))
+	centre = rng.choice(['northpole', 'southpole', 'seam', 'equator', 'highdec'])
+	tabs = []
+	for c in range(k):
+		n = int(rng.integers(1, 40 if c == 0 else 500))
+		spread = radius / 3600. * rng.uniform(3, 20)
+		if centre == 'northpole':
+			dec = 90 - np.abs(rng.normal(0, spread, size=n)); ra = rng.uniform(0, 360, size=n)
+		elif centre == 'southpole':
+			dec = -90 + np.abs(rng.normal(0, spread, size=n)); ra = rng.uniform(0, 360, size=n)
+		elif centre == 'seam':
+			dec = rng.normal(12, spread, size=n); ra = rng.normal(0, spread, size=n) % 360
+		elif centre == 'highdec':
+			dec = rng.normal(77, spread, size=n); ra = rng.normal(200, spread * 4, size=n) % 360
+		else:
+			dec = rng.normal(0, spread, size=n); ra = rng.normal(180, spread, size=n)
+		if c == 0 and n > 2 and centre.endswith('pole'):
+			dec[0] = 90.0 if centre == 'northpole' else -90.0
+		tabs.append(cat('T%d' % c, ra, np.clip(dec, -90, 90), rng.uniform(1, radius / 3) * np.ones(n), 41252.96))
+	return tabs, radius
+
+
+@pytest.mark.parametrize('seed', range(40))
+def test_random_configurations(seed):
+	import nway_amd as nw
+	rng = np.random.default_rng(1000 + seed)
+	k = int(rng.integers(2, 6))
+	tabs, radius = (flat_case if seed % 2 == 0 else sphere_case)(rng, k)
+	if seed % 2 == 1 and k > 4:
+		tabs = tabs[:4]
+	comp = float(rng.choice([1.0, 0.9, 0.5]))
+	rows = compare(nw, tabs, radius, comp, 'cli' if seed % 3 == 0 else 'api')
+	assert rows >= len(tabs[0]['ra'])
