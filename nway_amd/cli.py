@@ -7,9 +7,12 @@ as ``{TABLE}_{column}`` with -99 for absent counterparts, floats are written as 
 unrelated-association correction is the working one (nway.py:366-423), the auto-histogram
 selection indexes its weights by the selected rows (nway.py:471).
 
+Asymmetric / elliptical error columns (``:ra_err:dec_err``, ``:major:minor:angle``) use the
+device pipeline for the candidates and nway_amd/elliptical.py for the Bayes factors (parity
+unpinned: the reference needs astropy's SkyOffsetFrame).
+
 Not reproduced: the float32 round trip of the separations before log_bf (the
-outputs are float32 anyway), ``--prefilter-pair`` (broken upstream, fastskymatch.py:203),
-asymmetric / elliptical error columns (``:ra:dec``, ``:a:b:phi``) -- next in line.
+outputs are float32 anyway), ``--prefilter-pair`` (broken upstream, fastskymatch.py:203).
 """
 from __future__ import division, print_function
 
@@ -82,7 +85,10 @@ def resolve_errors(tables, table_names, pos_errors, match_radius_arcsec):
 		for k in keys:
 			assert k in t.data.dtype.names, 'ERROR: Position error column "%s" not in table "%s". Have these columns: %s' % (k, name, ', '.join(t.data.dtype.names))
 		if len(keys) > 1:
-			raise NotImplementedError('asymmetric / elliptical position errors ("%s") are not supported by the GPU build yet' % spec)
+			for key, meaning in zip(keys, ['ra_error', 'dec_error', 'ell_angle']):
+				print('    Position error for "%s": found column %s (for %s): Values are [%f..%f]' % (name, key, meaning, t.data[key].min(), t.data[key].max()))
+			errors.append(None)  # asymmetric / elliptical: handled by nway_amd.elliptical
+			continue
 		col = numpy.asarray(t.data[keys[0]], dtype=float)
 		print('    Position error for "%s": found column %s (for ra_error): Values are [%f..%f]' % (name, keys[0], col.min(), col.max()))
 		if col.min() <= 0:
@@ -201,12 +207,14 @@ def main(argv=None):
 	primary_id_key = '%s_%s' % (table_names[0], primary_id_key)
 
 	import nway_amd
-	match_tables = [dict(name=n, ra=numpy.asarray(t.data[rk], dtype=float), dec=numpy.asarray(t.data[dk], dtype=float), error=e, area=a)
+	simple_errors = all(e is not None for e in errors)
+	match_tables = [dict(name=n, ra=numpy.asarray(t.data[rk], dtype=float), dec=numpy.asarray(t.data[dk], dtype=float),
+		error=(e if simple_errors else 1.0), area=a)
 		for t, n, rk, dk, e, a in zip(tables, table_names, ra_keys, dec_keys, errors, areas)]
 	print('  computing probabilities ...')
-	correction = _hip.CORRECTION_CLI if args.consider_unrelated_associations else _hip.CORRECTION_NONE
+	correction = _hip.CORRECTION_CLI if (args.consider_unrelated_associations and simple_errors) else _hip.CORRECTION_NONE
 	res = nway_amd.run_match(match_tables, args.radius, completeness, args.acceptable_prob, correction=correction,
-		finalize=not args.mag, logger=nway_amd.NullOutputLogger())
+		finalize=(not args.mag) and simple_errors, logger=nway_amd.NullOutputLogger())
 	assert res.nrows > 0, 'No matches.'
 	print('matching: %6d matches after filtering by search radius' % res.nrows)
 	idx_columns = [res.to_host('idx', c).astype(numpy.int64) for c in range(k)]
@@ -223,15 +231,41 @@ def main(argv=None):
 				print('   setting "%s_%s" to -99 failed (%d affected; column format "%s"): %s' % (name, colname, missing.sum(), fmt, e))
 			columns.append(('%s_%s' % (name, colname), fmt, col))
 	pair_index = dict((p, n) for n, p in enumerate(_hip.pair_columns(k)))
+	sep_ra = [[None] * k for _ in range(k)]
+	sep_dec = [[None] * k for _ in range(k)]
 	for i in range(k):
 		for j in range(i):
 			columns.append(('Separation_%s_%s' % (table_names[i], table_names[j]), 'E', res.to_host('sep', pair_index[(j, i)])))
+			if not simple_errors:
+				# tangent-plane offsets, frame centred on the later catalogue's source (fastskymatch.py:306-312)
+				from . import elliptical
+				def coords(c):
+					m = idx_columns[c]
+					ra = numpy.where(m >= 0, match_tables[c]['ra'][m], -99.)
+					dec = numpy.where(m >= 0, match_tables[c]['dec'][m], -99.)
+					return ra, dec
+				dra, ddec = elliptical.offsets(*(coords(i) + coords(j)))
+				sep_ra[j][i], sep_dec[j][i] = dra * 60 * 60, ddec * 60 * 60
+				columns.append(('Separation_%s_%s_ra' % (table_names[i], table_names[j]), 'E', sep_ra[j][i]))
+				columns.append(('Separation_%s_%s_dec' % (table_names[i], table_names[j]), 'E', sep_dec[j][i]))
 	sep_max = res.to_host('sep_max')
 	ncat = res.to_host('ncat').astype(numpy.int64)
 	columns.append(('Separation_max', 'E', sep_max))
 	columns.append(('ncat', 'I', ncat))
-	log_bf_uncorrected = res.to_host('log_bf')
-	log_bf = res.to_host('log_bf_corrected')
+	prior = res.to_host('prior')
+	if simple_errors:
+		log_bf_uncorrected = res.to_host('log_bf')
+		log_bf = res.to_host('log_bf_corrected')
+	else:
+		from . import elliptical
+		triplets = elliptical.error_triplets(tables, table_names, pos_errors, idx_columns)
+		log_bf_uncorrected = elliptical.log_bf_table(k, idx_columns, sep_ra, sep_dec, triplets)
+		log_bf = log_bf_uncorrected
+		if args.consider_unrelated_associations and k >= 3:
+			dens = numpy.array([n / a * (4 * numpy.pi * (180 / numpy.pi)**2) for n, a in zip(sizes, areas)])
+			dens_plus = numpy.array([(n + 1) / a * (4 * numpy.pi * (180 / numpy.pi)**2) for n, a in zip(sizes, areas)])
+			dens_plus[0] = dens[0]
+			log_bf = elliptical.unrelated_associations(k, idx_columns, ncat, sep_ra, sep_dec, triplets, dens, dens_plus, log_bf_uncorrected)
 	columns.append(('dist_bayesfactor', 'E', log_bf_uncorrected))
 	if args.consider_unrelated_associations:
 		if (ncat <= k - 2).any():
@@ -239,7 +273,11 @@ def main(argv=None):
 			columns.append(('dist_bayesfactor_corrected', 'E', log_bf))
 		else:
 			print('      correcting for unrelated associations ... not necessary')
-	post = res.to_host('dist_post')
+	if simple_errors:
+		post = res.to_host('dist_post')
+	else:
+		from . import bayesdistance
+		post = bayesdistance.posterior(prior, log_bf)
 	columns.append(('dist_post', 'E', post))
 
 	biases = []
@@ -249,7 +287,7 @@ def main(argv=None):
 		t = _hip.torch()
 		lib = _hip.load()
 		device = res.plan.device
-		total = res.column('log_bf_corrected').clone()
+		total = res.column('log_bf_corrected').clone() if simple_errors else _hip.to_device(log_bf, device)
 		for mag, magfile in args.mag:
 			print('    magnitude bias "%s" ...' % mag)
 			col, ti, func, mag_all = cli_magnitude_bias(mag, magfile, table_names, tables, idx_columns, sep_max, post,
@@ -264,6 +302,12 @@ def main(argv=None):
 		print('Computing final probabilities ...')
 		from . import magpriors
 		stats = magpriors.final_probabilities_device(res, total, args.acceptable_prob)
+		p_single, p_any, p_i, flag = stats['p_single'], stats['p_any'], stats['p_i'], stats['match_flag']
+	elif not simple_errors:
+		print()
+		print('Computing final probabilities ...')
+		from . import magpriors
+		stats = magpriors.final_probabilities_device(res, _hip.to_device(log_bf, res.plan.device), args.acceptable_prob)
 		p_single, p_any, p_i, flag = stats['p_single'], stats['p_any'], stats['p_i'], stats['match_flag']
 	else:
 		print()

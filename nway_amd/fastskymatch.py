@@ -32,6 +32,18 @@ def dist(apos, bpos):
 	return res if shape else float(res)
 
 
+def dist3d(apos, bpos):
+	"""(separation, d_ra, d_dec) in degrees: great-circle separation (device) and the
+	tangent-plane offsets of b in the frame centred on a (fastskymatch.py:50-74; host numpy
+	restatement of astropy's SkyOffsetFrame, parity unpinned).  -99 marks absent sources."""
+	from . import elliptical
+	(a_ra, a_dec), (b_ra, b_dec) = apos, bpos
+	nan = lambda x: numpy.where(numpy.asarray(x, dtype=float) == -99, numpy.nan, numpy.asarray(x, dtype=float))
+	separation = dist((nan(a_ra), nan(a_dec)), (nan(b_ra), nan(b_dec)))
+	dra, ddec = elliptical.offsets(a_ra, a_dec, b_ra, b_dec)
+	return separation, dra, ddec
+
+
 def get_tablekeys(table, name, tablename=''):
 	"""column of ``table`` called ``name`` (case-insensitive), else the first one starting
 	with it (fastskymatch.py:77-80)"""

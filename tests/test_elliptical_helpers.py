@@ -72,3 +72,41 @@ def test_log_bf_elliptical_gpu():
 	one = np.ones(1)
 	ell = bd.log_bf_elliptical([[None, one]], [[None, 0 * one]], [bd.convert_from_ellipse(0.1 * one, 0.1 * one, 0), bd.convert_from_ellipse(0.2 * one, 0.2 * one, 0)])
 	np.testing.assert_allclose(ell, bd.log_bf([[None, one]], [0.1 * one, 0.2 * one]), rtol=1e-9)
+
+
+@pytest.mark.gpu
+def test_cli_elliptical_columns_reduce_to_circular(tmp_path, monkeypatch):
+	"""`:a:b:phi` and `:ra_err:dec_err` error columns (nway.py:52-88): with a == b the elliptical
+	run must reproduce the circular one; the per-axis separation columns appear"""
+	from goldenutil import ell_tables
+	from nway_amd import _fits, cli
+	monkeypatch.chdir(tmp_path)
+	X, R, O = ell_tables()
+	rng = np.random.RandomState(4)
+	for t in (X, R):
+		n = len(t['ra'])
+		e = t['error']
+		_fits.write_table('%s.fits' % t['name'], [('ID', 'J', np.arange(1, n + 1)), ('RA', 'D', t['ra']), ('DEC', 'D', t['dec']),
+			('pos_err', 'D', e), ('a', 'D', e), ('b', 'D', e), ('phi', 'D', rng.uniform(0, 180, n)),
+			('a2', 'D', e * 1.5), ('b2', 'D', e * 0.7)], t['name'], table_header={'SKYAREA': t['area']})
+	n = len(O['ra'])
+	_fits.write_table('OPT.fits', [('ID', 'J', np.arange(1, n + 1)), ('RA', 'D', O['ra']), ('DEC', 'D', O['dec'])], 'OPT', table_header={'SKYAREA': O['area']})
+	base = ['--radius', '10', '--min-prob', '0.01']
+	assert cli.main(base + ['CHANDRA.fits', ':pos_err', 'XMM.fits', ':pos_err', 'OPT.fits', '0.1', '--out', 'circ.fits']) == 0
+	assert cli.main(base + ['CHANDRA.fits', ':a:b:phi', 'XMM.fits', ':a:b', 'OPT.fits', '0.1', '--out', 'ell.fits']) == 0
+	circ, ell = _fits.read_table('circ.fits'), _fits.read_table('ell.fits')
+	for c in ('Separation_OPT_CHANDRA_ra', 'Separation_OPT_CHANDRA_dec', 'Separation_OPT_XMM_ra', 'Separation_XMM_CHANDRA_dec'):
+		assert c in ell.names
+	assert len(circ.data) == len(ell.data)
+	np.testing.assert_array_equal(circ.data['OPT_ID'], ell.data['OPT_ID'])
+	np.testing.assert_array_equal(circ.data['match_flag'], ell.data['match_flag'])
+	for c in ('dist_bayesfactor', 'dist_bayesfactor_corrected', 'dist_post', 'p_any', 'p_i'):
+		np.testing.assert_allclose(ell.data[c], circ.data[c], rtol=2e-4, atol=1e-6, err_msg=c)
+	# per-axis offsets are consistent with the great-circle separation
+	both = ell.data['OPT_ID'] != -99
+	sep = np.hypot(ell.data['Separation_OPT_CHANDRA_ra'][both], ell.data['Separation_OPT_CHANDRA_dec'][both])
+	np.testing.assert_allclose(sep, ell.data['Separation_OPT_CHANDRA'][both], rtol=1e-4, atol=1e-4)
+	# genuinely elliptical errors run and change the answer
+	assert cli.main(base + ['CHANDRA.fits', ':a2:b2:phi', 'OPT.fits', '0.1', '--out', 'ell2.fits']) == 0
+	e2 = _fits.read_table('ell2.fits')
+	assert len(e2.data) > 100 and np.isfinite(e2.data['p_i']).all()
