@@ -51,6 +51,8 @@ extern "C" {
 #define NWAYHIP_FLAG_PAIR_OVERFLOW 1     /* cap_pairs too small: results invalid, retry larger */
 #define NWAYHIP_FLAG_ROW_OVERFLOW 2      /* cap_rows too small: results invalid, retry larger */
 #define NWAYHIP_FLAG_REG_OVERFLOW 4      /* registration table too small */
+#define NWAYHIP_FLAG_SLOT_OVERFLOW 8     /* a primary has more links than link_slots: repeat with link_slots = -1 */
+#define NWAYHIP_FLAG_LOOKBACK 16         /* the single-pass scan timed out: repeat with link_slots = -1 */
 
 typedef struct nwayhip_catalogue {
 	const double* ra;                    /* degrees */
@@ -68,7 +70,9 @@ typedef struct nwayhip_match_params {
 	int32_t correction;                  /* NWAYHIP_CORRECTION_* */
 	int32_t finalize;                    /* 1: also run the per-primary group statistics with
 	                                        total = dist_bayesfactor (no magnitude biases) */
-	int32_t reserved;
+	int32_t link_slots;                  /* 2-catalogue sparse fast path: links kept in this many fixed slots
+	                                        per primary and the tail fused into one launch.  0 = decide from
+	                                        the densities, -1 = never, > 0 = force that many slots */
 	double err_deg;                      /* cell size: match_radius / 60. / 60 (__init__.py:128) */
 	double radius_arcsec;                /* match_radius */
 	double prob_ratio_secondary;         /* __init__.py:33 */

@@ -18,7 +18,7 @@ MAXPAIR = 28
 STATUS_WORDS = 32
 ST_ROWS, ST_FLAGS, ST_REGISTRATIONS, ST_TESTS = 0, 1, 2, 3
 ST_SURVIVORS, ST_PAIRS, ST_NOTFLAT = 8, 16, 24
-FLAG_PAIR_OVERFLOW, FLAG_ROW_OVERFLOW, FLAG_REG_OVERFLOW = 1, 2, 4
+FLAG_PAIR_OVERFLOW, FLAG_ROW_OVERFLOW, FLAG_REG_OVERFLOW, FLAG_SLOT_OVERFLOW, FLAG_LOOKBACK = 1, 2, 4, 8, 16
 SCHEME_FLAT, SCHEME_SPHERE = 0, 1
 STAGES = 8
 STAGE_NAMES = ['register', 'sweep', 'pairs', 'lists', 'expand', 'rows', 'groups']
@@ -36,7 +36,7 @@ class Catalogue(ctypes.Structure):
 
 class MatchParams(ctypes.Structure):
 	_fields_ = [('ncat', ctypes.c_int32), ('scheme', ctypes.c_int32), ('radius_filter', ctypes.c_int32),
-		('correction', ctypes.c_int32), ('finalize', ctypes.c_int32), ('reserved', ctypes.c_int32),
+		('correction', ctypes.c_int32), ('finalize', ctypes.c_int32), ('link_slots', ctypes.c_int32),
 		('err_deg', ctypes.c_double), ('radius_arcsec', ctypes.c_double), ('prob_ratio_secondary', ctypes.c_double),
 		('dens', ctypes.c_double * MAXCAT), ('dens_plus', ctypes.c_double * MAXCAT),
 		('prior_table', ctypes.c_double * (1 << (MAXCAT - 1))),
@@ -267,8 +267,9 @@ class MatchPlan(object):
 
 
 def make_params(ncat, scheme, radius_arcsec, err_deg, dens, dens_plus, prior_table, prob_ratio_secondary=0.5,
-		radius_filter=True, correction=CORRECTION_NONE, finalize=True, sphere_cell_factor=0.0, bitmap_bits=0):
+		radius_filter=True, correction=CORRECTION_NONE, finalize=True, sphere_cell_factor=0.0, bitmap_bits=0, link_slots=0):
 	p = MatchParams()
+	p.link_slots = link_slots
 	p.ncat = ncat
 	p.scheme = scheme
 	p.radius_filter = 1 if radius_filter else 0
@@ -297,6 +298,12 @@ def run_plan(sizes, params, catalogues, cap_pairs, cap_rows, device, max_retries
 		if flags & FLAG_REG_OVERFLOW:
 			plan.close()
 			raise NwayHipError('primary cell registration overflowed (sources piled up on a pole?)')
+		if flags & (FLAG_SLOT_OVERFLOW | FLAG_LOOKBACK):
+			# the sparse 2-way fast path does not fit this input: repeat on the general path
+			params.link_slots = -1
+			plan.close()
+			del plan
+			continue
 		if flags & (FLAG_PAIR_OVERFLOW | FLAG_ROW_OVERFLOW):
 			need_pairs = int(max(st[ST_PAIRS:ST_PAIRS + 8]))
 			cap_pairs = max(cap_pairs, int(need_pairs * 1.05) + 1024)

@@ -36,6 +36,7 @@
 #include "expand.inc"
 #include "rows.inc"
 #include "finish2.inc"
+#include "tail2.inc"
 #include "elementwise.inc"
 #include "api.inc"
 #include "plan.inc"

@@ -271,3 +271,31 @@ def test_nwaylib_alias(nw):
 	import nwaylib.bayesdistance as bd
 	assert nwaylib.nway_match is nw.nway_match and nwaylib.__version__ == '4.7.1'
 	assert bd.log_bf2(0.3, 0.1, 0.2) == pytest.approx(11.840045223967955, rel=1e-14)
+
+
+def test_sparse_fast_path_and_its_fallback(nw):
+	"""2-way sparse inputs take the fused tail (links in fixed slots + single-pass scan); a primary
+	with more links than slots makes the run fall back to the general path; both paths and the
+	general path forced from the start give the identical table"""
+	from nway_amd import _hip
+	rng = np.random.RandomState(31)
+	n0, n1 = 70000, 400000
+	a = cat('A', rng.uniform(0, 360, n0), np.degrees(np.arcsin(rng.uniform(-1, 1, n0))), rng.uniform(0.5, 2, n0), 41252.96)
+	b = cat('B', rng.uniform(0, 360, n1), np.degrees(np.arcsin(rng.uniform(-1, 1, n1))), 0.3 * np.ones(n1), 41252.96)
+	b['ra'][:50000] = a['ra'][:50000] + rng.normal(0, 1, 50000) / 3600.
+	b['dec'][:50000] = np.clip(a['dec'][:50000] + rng.normal(0, 1, 50000) / 3600., -90, 90)
+	# primary 7 gets five counterparts
+	b['ra'][60000:60004] = a['ra'][7]; b['dec'][60000:60004] = np.clip(a['dec'][7] + np.arange(1, 5) * 1e-4, -90, 90)
+	tables = {}
+	for slots in (0, 2, -1):
+		res = nw.run_match([a, b], 10., 0.9, link_slots=slots, logger=nw.NullOutputLogger())
+		assert int(res.status[_hip.ST_FLAGS]) == 0
+		if slots == 2:
+			assert res.plan.params.link_slots == -1  # fell back
+		tables[slots] = dict(idx1=res.to_host('idx', 1), p_i=res.to_host('p_i'), p_any=res.to_host('p_any'), flag=res.to_host('match_flag'),
+			bf=res.to_host('log_bf'), gs=res.plan.cols['group_start'].cpu().numpy())
+		res.plan.close()
+	assert (tables[0]['idx1'] >= 0).sum() > 50000
+	for key in tables[0]:
+		np.testing.assert_array_equal(tables[0][key], tables[-1][key], err_msg=key)
+		np.testing.assert_array_equal(tables[2][key], tables[-1][key], err_msg=key)
