@@ -1,15 +1,21 @@
-"""Loggers with the interface of nwaylib/logger.py:28-53 (``log``, ``warn``, ``progress``)."""
+"""Message sinks accepted by every ``logger=`` argument of the package.
+
+Same surface as the reference's logger module (``NormalLogger``, ``NullOutputLogger``,
+``FakeProgressBar``; methods ``log``, ``warn``, ``progress``), so objects written for nwaylib
+can be passed in unchanged.  Warnings always go through the ``warnings`` module; only the
+destination of ordinary messages differs between the two loggers.
+"""
 from __future__ import division, print_function
 
 import sys
 import warnings
 
 
-class _PassThrough(object):
-	"""progress "bar" that does nothing; iterating over it yields the wrapped iterable"""
+class FakeProgressBar(object):
+	"""Stands in for a progress bar: wraps an iterable without reporting anything."""
 
-	def __init__(self, *args, **kwargs):
-		pass
+	def __init__(self, *unused_args, **unused_kwargs):
+		self.steps = 0
 
 	def __call__(self, iterable):
 		return iterable
@@ -18,36 +24,37 @@ class _PassThrough(object):
 		return self
 
 	def increment(self):
-		pass
+		self.steps += 1
 
 	def finish(self):
-		pass
+		return None
 
 
-FakeProgressBar = _PassThrough
+class _Logger(object):
+	stream = None  # file-like object for ordinary messages, None = discard
 
+	def log(self, *messages):
+		if self.stream is not None:
+			self.stream.write(' '.join(str(m) for m in messages) + '\n')
 
-class NullOutputLogger(object):
-	"""silent logger"""
-
-	def log(self, *msg):
-		pass
-
-	def warn(self, msg):
-		warnings.warn(msg, stacklevel=3)
+	def warn(self, message):
+		# stacklevel 3: attribute the warning to the caller of the library function
+		warnings.warn(message, stacklevel=3)
 
 	def progress(self, *args, **kwargs):
-		return _PassThrough()
+		return FakeProgressBar()
 
 
-class NormalLogger(object):
-	"""messages go to stderr, one per line"""
+class NullOutputLogger(_Logger):
+	"""keeps quiet (warnings are still raised through ``warnings``)"""
 
-	def log(self, msg):
-		sys.stderr.write('%s\n' % msg)
 
-	def warn(self, msg):
-		warnings.warn(msg, stacklevel=3)
+class NormalLogger(_Logger):
+	"""one line per message on stderr; tqdm progress bars when tqdm is installed"""
+
+	@property
+	def stream(self):
+		return sys.stderr
 
 	def progress(self, ndigits=6, *args, **kwargs):
 		from . import progress
