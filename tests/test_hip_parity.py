@@ -299,3 +299,38 @@ def test_sparse_fast_path_and_its_fallback(nw):
 	for key in tables[0]:
 		np.testing.assert_array_equal(tables[0][key], tables[-1][key], err_msg=key)
 		np.testing.assert_array_equal(tables[2][key], tables[-1][key], err_msg=key)
+
+
+@pytest.mark.parametrize('nfiles,ngen', [(2, 1000), (3, 400), (4, 100), (5, 40)])
+def test_match_multiple_like_reference_tests(nw, tmp_path, monkeypatch, nfiles, ngen):
+	"""tests/fastskymatch_test.py:31-72,109-119 of the reference: random float32 catalogues in
+	the unit square (all-sky scheme: RA < 10 err), matched through the FITS-flavoured
+	match_multiple and written out; the reference asserts only len > 20 -- here also checked
+	against the oracle"""
+	from nway_amd import _fits, progress
+	from nway_amd.fastskymatch import array2fits, match_multiple, wraptable2fits, fits_from_columns
+	monkeypatch.chdir(tmp_path)
+	np.random.seed(0)
+	filenames = ['test_input_%d.fits' % i for i in range(nfiles)]
+	for fitsname in filenames:
+		ra = np.random.uniform(size=ngen)
+		dec = np.random.uniform(size=ngen)
+		data = np.array(list(zip(ra, dec)), dtype=[('ra', 'f'), ('dec', 'f')])
+		hdu = array2fits(data, fitsname.replace('.fits', ''))
+		hdu.writeto(fitsname, **progress.kwargs_overwrite_true)
+	tables = [_fits.read_table(f) for f in filenames]
+	table_names = [t.name for t in tables]
+	err = 0.03
+	results, columns, header = match_multiple([t.data for t in tables], table_names, err, [t.formats for t in tables], logger=nw.NullOutputLogger())
+	hdu = wraptable2fits(fits_from_columns(columns), 'MATCH')
+	hdu.writeto('test_match%d.fits' % nfiles, **progress.kwargs_overwrite_true)
+	back = _fits.read_table('test_match%d.fits' % nfiles)
+	for name in table_names:
+		ra = back.data['%s_ra' % name]
+		assert len(ra) > 20 and len(back.data['%s_dec' % name]) == len(ra)
+	assert header['COLS_RA'] == ' '.join('%s_ra' % n for n in table_names)
+	# index table against the oracle on the same (float32 -> float64) coordinates
+	tabs = [(np.asarray(t.data['ra'], dtype=float), np.asarray(t.data['dec'], dtype=float)) for t in tables]
+	want = orc.enumerate_tuples(tabs, err, orc.SPHERE, err * 60 * 60)
+	got = np.stack([results[n] for n in table_names], axis=1)
+	np.testing.assert_array_equal(got, want)
