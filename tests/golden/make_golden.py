@@ -12,7 +12,10 @@ executed on
   * its shipped fixtures tests/elltest/randomcat{X,R,O}.fits (2-way and 3-way),
   * its shipped doc/COSMOS_XMM.fits against seeded uniform stand-ins for the two
     catalogues that are missing from the checkout (.MISSING_LARGE_BLOBS),
-  * small adversarial tables (negative declination cells, lone primaries, ties).
+  * small adversarial tables (negative declination cells, lone primaries, ties),
+  * all-sky tables (both poles, the RA = 0/360 seam) through the reference's HEALPix branch with
+    oracle/healpix.py standing in for the absent healpy (see ref_harness.py: pins the branch
+    logic, not healpy's pixel numbering).
 Outputs are .npz files holding INPUTS and EXPECTED OUTPUTS only (data, no code).
 """
 import os
@@ -29,7 +32,7 @@ from ref_harness import load_reference, REFERENCE  # noqa: E402
 from nway_amd import _fits  # noqa: E402
 
 warnings.simplefilter('ignore')
-ref = load_reference()
+ref = load_reference(healpix=True)
 LOG = ref.NullOutputLogger()
 raw_crossproduct = ref.match.crossproduct.func
 
@@ -450,3 +453,61 @@ if __name__ == '__main__' and ('mag' in sys.argv[1:] or not sys.argv[1:]):
 	gen_mag()
 if __name__ == '__main__' and ('ellmath' in sys.argv[1:] or not sys.argv[1:]):
 	gen_ellmath()
+
+
+def _scatter(rng, ra, dec, sigma_arcsec):
+	"""positions displaced by an isotropic gaussian of the given width; valid at the poles"""
+	lon, lat = np.radians(ra), np.radians(dec)
+	v = np.stack([np.cos(lat) * np.cos(lon), np.cos(lat) * np.sin(lon), np.sin(lat)], axis=1)
+	v = v + rng.normal(size=v.shape) * np.radians(sigma_arcsec / 3600.)
+	v /= np.sqrt((v ** 2).sum(axis=1))[:, None]
+	return np.degrees(np.arctan2(v[:, 1], v[:, 0])) % 360., np.degrees(np.arcsin(np.clip(v[:, 2], -1, 1)))
+
+
+def gen_allsky():
+	"""3-way and 2-way all-sky matches; takes the HEALPix branch (fastskymatch.py:99-160)"""
+	rng = np.random.RandomState(77)
+	radius = 20.
+	npole, nseam, nfree = 300, 300, 600
+	ra = np.concatenate([rng.uniform(0, 360, npole), rng.uniform(0, 360, npole),
+		np.mod(rng.normal(0, 0.02, nseam), 360.), rng.uniform(0, 360, nfree)])
+	dec = np.concatenate([90 - np.abs(rng.normal(0, 0.5, npole)), -90 + np.abs(rng.normal(0, 0.5, npole)),
+		rng.uniform(-60, 60, nseam), np.degrees(np.arcsin(rng.uniform(-1, 1, nfree)))])
+	ra[0], dec[0] = 0.0, 90.0       # exactly on the pole
+	ra[npole], dec[npole] = 123.0, -90.0
+	ra[2 * npole] = 0.0             # exactly on the seam
+	ra[2 * npole + 1] = 359.9999999
+	n0 = len(ra)
+	def secondary(frac, sigma, nfield, nrandom):
+		has = np.flatnonzero(rng.uniform(size=n0) < frac)
+		parts = [_scatter(rng, ra[has], dec[has], sigma)]
+		for _ in range(nfield):
+			parts.append(_scatter(rng, ra, dec, 25.))
+		parts.append((rng.uniform(0, 360, nrandom), np.degrees(np.arcsin(rng.uniform(-1, 1, nrandom)))))
+		r, d = np.concatenate([q[0] for q in parts]), np.concatenate([q[1] for q in parts])
+		order = rng.permutation(len(r))
+		return r[order], d[order]
+	b_ra, b_dec = secondary(0.8, 3., 6, 3000)
+	c_ra, c_dec = secondary(0.6, 2., 4, 2000)
+	area = 41252.96
+	ta = cat('A', ra, dec, rng.uniform(1, 4, size=n0), area)
+	tb = cat('B', b_ra, b_dec, 0.5 * np.ones(len(b_ra)), area)
+	tc = cat('C', c_ra, c_dec, 1.0 * np.ones(len(c_ra)), area)
+	out = dict(radius=np.array([radius]), completeness=np.array([0.9]), area=np.array([area]))
+	for i, t in enumerate((ta, tb, tc)):
+		out['ra%d' % i], out['dec%d' % i], out['err%d' % i] = t['ra'], t['dec'], t['error']
+	cp = raw_crossproduct([(t['ra'], t['dec']) for t in (ta, tb)], radius / 60 / 60, LOG)
+	out['w2_crossproduct_nrows'] = np.array([len(cp)])
+	res = run([ta, tb], radius, 0.9)
+	out.update(table_arrays(res, ['A', 'B'], 'w2_'))
+	cp = raw_crossproduct([(t['ra'], t['dec']) for t in (ta, tb, tc)], radius / 60 / 60, LOG)
+	out['w3_crossproduct_nrows'] = np.array([len(cp)])
+	res = run([ta, tb, tc], radius, 0.9)
+	out.update(table_arrays(res, ['A', 'B', 'C'], 'w3_'))
+	out.update(cli_correction_prefixed(ref, [ta, tb, tc], radius, 0.9, 'w3_'))
+	print('allsky: 2-way %d rows, 3-way %d rows (pre-filter %d)' % (len(out['w2_idx']), len(out['w3_idx']), len(cp)))
+	save('allsky', **out)
+
+
+if __name__ == '__main__' and ('allsky' in sys.argv[1:] or not sys.argv[1:]):
+	gen_allsky()

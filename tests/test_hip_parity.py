@@ -119,6 +119,22 @@ def test_xmm_standins_golden(nw):
 	assert_table_matches(t3, g, 'w3_sub_', ['XMM', 'OPT', 'IRAC'], rows=g['w3_sub_rows'])
 
 
+def test_allsky_golden(nw):
+	"""both poles and the RA seam: tables produced by the reference's HEALPix branch (over
+	oracle/healpix.py in place of healpy, see tests/golden/ref_harness.py)"""
+	g = golden('allsky')
+	tabs = [cat('ABC'[i], g['ra%d' % i], g['dec%d' % i], g['err%d' % i], g['area'][0]) for i in range(3)]
+	radius, c = float(g['radius'][0]), float(g['completeness'][0])
+	cp = nw.match.crossproduct([(x['ra'], x['dec']) for x in tabs[:2]], radius / 60 / 60)
+	np.testing.assert_array_equal(cp, g['w2_idx'])
+	assert_table_matches(run(nw, tabs[:2], radius, c), g, 'w2_', ['A', 'B'])
+	assert_table_matches(run(nw, tabs, radius, c), g, 'w3_', ['A', 'B', 'C'])
+	tc = run(nw, tabs, radius, c, unrelated_associations='cli')
+	delta = tc['dist_bayesfactor'] - tc['dist_bayesfactor_uncorrected']
+	np.testing.assert_array_equal(np.flatnonzero(delta != 0), g['w3_cli_changed_rows'])
+	np.testing.assert_allclose(delta[delta != 0], g['w3_cli_correction'], rtol=1e-6)
+
+
 def test_edge_cases_golden(nw):
 	g = golden('edge')
 	tabs = [cat('ABC'[i], g['neg_ra%d' % i], g['neg_dec%d' % i], g['neg_err%d' % i], g['neg_area'][0]) for i in range(3)]
