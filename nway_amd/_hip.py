@@ -75,7 +75,8 @@ _lib = None
 
 
 def library_path():
-	return _build.LIBRARY
+	"""the in-tree build, or the prebuilt library named by $NWAYHIP_LIBRARY"""
+	return os.environ.get('NWAYHIP_LIBRARY') or _build.LIBRARY
 
 
 def load():
