@@ -245,6 +245,31 @@ def test_flat_scheme_random_vs_oracle(nw):
 	oracle_vs_hip(nw, [a, b, c, d], 25., np.array([1.0, 0.9, 0.8, 0.7]), ['A', 'B', 'C', 'D'], correction='cli')
 
 
+def test_flat_cells_on_cell_borders(nw):
+	"""coordinates that are exact multiples of the cell size, or a few ulps either side of
+	one: ``int(ra / err)`` (fastskymatch.py:125) must come out as with the true division (the
+	kernels multiply by 1/err and divide only where the two could differ)"""
+	rng = np.random.RandomState(21)
+	for err_arcsec in (10., 7., 3.3):
+		err = err_arcsec / 60 / 60
+		def border(n, lo_cell, span):
+			cells = rng.randint(lo_cell, lo_cell + span, size=n).astype(float)
+			x = cells * err
+			kind = rng.randint(0, 6, size=n)
+			for k, steps in ((1, 1), (2, -1), (3, 3), (4, -3)):
+				sel = kind == k
+				y = x[sel]
+				for _ in range(abs(steps)):
+					y = np.nextafter(y, np.inf if steps > 0 else -np.inf)
+				x[sel] = y
+			x[kind == 5] += rng.uniform(0, 1, size=(kind == 5).sum()) * err
+			return x
+		lo = int(30. / err)
+		tabs = [(border(n, lo, 40), border(n, -20, 40)) for n in (300, 6000, 5000)]
+		cp = nw.match.crossproduct(tabs, err)
+		np.testing.assert_array_equal(cp, orc.crossproduct(tabs, err))
+
+
 def test_cli_fits_in_fits_out(nw, tmp_path, monkeypatch):
 	"""nway.py surface: FITS catalogues in, FITS table out (columns, order and formats of
 	SURVEY.md appendix C); values = the API's, stored as float32"""
