@@ -83,6 +83,8 @@ typedef struct nwayhip_match_params {
 	double prior_table[1 << (NWAYHIP_MAXCAT - 1)];
 	double sphere_cell_factor;           /* all-sky cell edge in units of the radius (0 = default) */
 	int64_t bitmap_bits;                 /* 0 = default; power of two */
+	int64_t table_slots;                 /* cell-table slots (rounded up to a power of two); 0 = default sizing.
+	                                      * NWAYHIP_FLAG_REG_OVERFLOW asks the caller to come back with more. */
 } nwayhip_match_params;
 
 /* Output table, SoA, `capacity` rows allocated by the caller.  Columns follow
@@ -134,6 +136,8 @@ int nwayhip_plan_create(nwayhip_plan** plan, const nwayhip_match_params* params,
 	int64_t cap_pairs, int64_t cap_rows);
 int nwayhip_plan_destroy(nwayhip_plan* plan);
 size_t nwayhip_plan_workspace_bytes(const nwayhip_plan* plan);
+/* slots of the plan's cell table (what to multiply when NWAYHIP_FLAG_REG_OVERFLOW comes back) */
+int64_t nwayhip_plan_table_slots(const nwayhip_plan* plan);
 /* Enqueue the whole pipeline on `stream`.  d_status: device int64[NWAYHIP_STATUS_WORDS]. */
 int nwayhip_match_enqueue(nwayhip_plan* plan, const nwayhip_catalogue* h_cats, void* workspace,
 	size_t workspace_bytes, const nwayhip_table* h_table, int64_t* d_status, void* stream);

@@ -134,7 +134,7 @@ class MatchResult(object):
 
 def run_match(match_tables, match_radius, prior_completeness=1.0, prob_ratio_secondary=0.5,
 		radius_filter=True, correction=_hip.CORRECTION_NONE, finalize=True, scheme=None, device=None,
-		logger=None, sphere_cell_factor=0.0, bitmap_bits=0, err_deg=None, link_slots=0):
+		logger=None, sphere_cell_factor=0.0, bitmap_bits=0, err_deg=None, link_slots=0, table_slots=0):
 	"""Upload the catalogues and run the whole HIP pipeline once; returns a MatchResult."""
 	logger = logger or NullOutputLogger()
 	device = _hip.require_device(device)
@@ -154,7 +154,7 @@ def run_match(match_tables, match_radius, prior_completeness=1.0, prob_ratio_sec
 	params = _hip.make_params(ncats, scheme, float(match_radius), err, dens, dens_plus,
 		_prior_table(dens, dens_plus, completeness), prob_ratio_secondary=prob_ratio_secondary,
 		radius_filter=radius_filter, correction=correction, finalize=finalize,
-		sphere_cell_factor=sphere_cell_factor, bitmap_bits=bitmap_bits, link_slots=link_slots)
+		sphere_cell_factor=sphere_cell_factor, bitmap_bits=bitmap_bits, link_slots=link_slots, table_slots=table_slots)
 	cats = [_hip.DeviceCatalogue(ra, dec, numpy.asarray(t['error'], dtype=float), device) for (ra, dec), t in zip(ratables, match_tables)]
 	sizes = [c.n for c in cats]
 	cap_pairs, cap_rows = _estimate_capacities(sizes, [t['area'] * 1.0 for t in match_tables], match_radius, scheme, radius_filter)

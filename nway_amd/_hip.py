@@ -40,7 +40,7 @@ class MatchParams(ctypes.Structure):
 		('err_deg', ctypes.c_double), ('radius_arcsec', ctypes.c_double), ('prob_ratio_secondary', ctypes.c_double),
 		('dens', ctypes.c_double * MAXCAT), ('dens_plus', ctypes.c_double * MAXCAT),
 		('prior_table', ctypes.c_double * (1 << (MAXCAT - 1))),
-		('sphere_cell_factor', ctypes.c_double), ('bitmap_bits', ctypes.c_int64)]
+		('sphere_cell_factor', ctypes.c_double), ('bitmap_bits', ctypes.c_int64), ('table_slots', ctypes.c_int64)]
 
 
 class Table(ctypes.Structure):
@@ -63,6 +63,7 @@ SYMBOLS = {
 	'nwayhip_plan_create': (ctypes.c_int, [ctypes.POINTER(_vp), ctypes.POINTER(MatchParams), ctypes.POINTER(_i64), _i64, _i64]),
 	'nwayhip_plan_destroy': (ctypes.c_int, [_vp]),
 	'nwayhip_plan_workspace_bytes': (ctypes.c_size_t, [_vp]),
+	'nwayhip_plan_table_slots': (ctypes.c_int64, [_vp]),
 	'nwayhip_match_enqueue': (ctypes.c_int, [_vp, ctypes.POINTER(Catalogue), _vp, ctypes.c_size_t, ctypes.POINTER(Table), _vp, _vp]),
 	'nwayhip_plan_profile': (ctypes.c_int, [_vp, ctypes.c_uint32]),
 	'nwayhip_plan_profile_read': (ctypes.c_int, [_vp, ctypes.POINTER(_i64), ctypes.POINTER(_dbl)]),
@@ -193,6 +194,9 @@ class DeviceCatalogue(object):
 class MatchPlan(object):
 	"""Parameters + capacities + device buffers for repeated runs of the match pipeline."""
 
+	def table_slots(self):
+		return self._table_slots
+
 	def __init__(self, sizes, params, cap_pairs, cap_rows, device):
 		t = torch()
 		self.lib = load()
@@ -207,6 +211,7 @@ class MatchPlan(object):
 		check(self.lib.nwayhip_plan_create(ctypes.byref(handle), ctypes.byref(params), n_arr, self.cap_pairs, self.cap_rows))
 		self.handle = handle
 		self.workspace_bytes = int(self.lib.nwayhip_plan_workspace_bytes(handle))
+		self._table_slots = int(self.lib.nwayhip_plan_table_slots(handle))
 		with t.cuda.device(self.device):
 			self.workspace = t.empty(self.workspace_bytes + 256, dtype=t.uint8, device=self.device)
 			self.status = t.zeros(STATUS_WORDS, dtype=t.int64, device=self.device)
@@ -268,8 +273,9 @@ class MatchPlan(object):
 
 
 def make_params(ncat, scheme, radius_arcsec, err_deg, dens, dens_plus, prior_table, prob_ratio_secondary=0.5,
-		radius_filter=True, correction=CORRECTION_NONE, finalize=True, sphere_cell_factor=0.0, bitmap_bits=0, link_slots=0):
+		radius_filter=True, correction=CORRECTION_NONE, finalize=True, sphere_cell_factor=0.0, bitmap_bits=0, link_slots=0, table_slots=0):
 	p = MatchParams()
+	p.table_slots = table_slots
 	p.link_slots = link_slots
 	p.ncat = ncat
 	p.scheme = scheme
@@ -297,8 +303,15 @@ def run_plan(sizes, params, catalogues, cap_pairs, cap_rows, device, max_retries
 		st = plan.read_status()
 		flags = int(st[ST_FLAGS])
 		if flags & FLAG_REG_OVERFLOW:
+			# the cell table is sized for the expected registrations per primary; catalogues piled
+			# up near a pole need more: come back with a larger table (bounded)
+			slots = plan.table_slots() * 4
 			plan.close()
-			raise NwayHipError('primary cell registration overflowed (sources piled up on a pole?)')
+			del plan
+			if slots > 256 * max(int(sizes[0]), 1) + (1 << 16):
+				raise NwayHipError('primary cell registration overflowed (sources piled up on a pole?)')
+			params.table_slots = slots
+			continue
 		if flags & (FLAG_SLOT_OVERFLOW | FLAG_LOOKBACK):
 			# the sparse 2-way fast path does not fit this input: repeat on the general path
 			params.link_slots = -1

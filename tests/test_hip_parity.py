@@ -342,6 +342,27 @@ def test_sparse_fast_path_and_its_fallback(nw):
 		np.testing.assert_array_equal(tables[2][key], tables[-1][key], err_msg=key)
 
 
+def test_cell_table_overflow_grows_the_table(nw):
+	"""a cell table that is too small for the registrations (sources piled up on a pole need many
+	cells each) is flagged and the run repeated with a larger one: same table as a roomy run"""
+	from nway_amd import _hip
+	rng = np.random.RandomState(32)
+	n0, n1 = 4000, 60000
+	a = cat('A', rng.uniform(0, 360, n0), 90 - np.abs(rng.normal(0, 0.05, n0)), rng.uniform(0.5, 2, n0), 41252.96)
+	b = cat('B', rng.uniform(0, 360, n1), 90 - np.abs(rng.normal(0, 0.05, n1)), 0.3 * np.ones(n1), 41252.96)
+	out = {}
+	for slots in (1024, 1 << 22):
+		res = nw.run_match([a, b], 10., 0.9, table_slots=slots, logger=nw.NullOutputLogger())
+		assert int(res.status[_hip.ST_FLAGS]) == 0
+		if slots == 1024:
+			assert res.plan.table_slots() > 1024 and int(res.status[_hip.ST_REGISTRATIONS]) > 1024
+		out[slots] = dict(idx1=res.to_host('idx', 1), p_i=res.to_host('p_i'), flag=res.to_host('match_flag'))
+		res.plan.close()
+	for key in out[1024]:
+		np.testing.assert_array_equal(out[1024][key], out[1 << 22][key], err_msg=key)
+	oracle_vs_hip(nw, [a, b], 10., 0.9, ['A', 'B'], oracle=orc_c)
+
+
 @pytest.mark.parametrize('nfiles,ngen', [(2, 1000), (3, 400), (4, 100), (5, 40)])
 def test_match_multiple_like_reference_tests(nw, tmp_path, monkeypatch, nfiles, ngen):
 	"""tests/fastskymatch_test.py:31-72,109-119 of the reference: random float32 catalogues in
