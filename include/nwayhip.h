@@ -138,7 +138,11 @@ int nwayhip_plan_destroy(nwayhip_plan* plan);
 size_t nwayhip_plan_workspace_bytes(const nwayhip_plan* plan);
 /* slots of the plan's cell table (what to multiply when NWAYHIP_FLAG_REG_OVERFLOW comes back) */
 int64_t nwayhip_plan_table_slots(const nwayhip_plan* plan);
-/* Enqueue the whole pipeline on `stream`.  d_status: device int64[NWAYHIP_STATUS_WORDS]. */
+/* Enqueue the whole pipeline on `stream`.  d_status: device int64[NWAYHIP_STATUS_WORDS].
+ * The workspace's contents may be arbitrary the first time a plan sees it (the plan clears what
+ * it needs); between runs of the same plan on the same workspace they must be left alone (by
+ * the caller and by other plans) -- the cell table is epoch-tagged and not cleared again.  Handing the plan a different workspace
+ * pointer is always safe; after scribbling over a workspace, destroy the plan and make a new one. */
 int nwayhip_match_enqueue(nwayhip_plan* plan, const nwayhip_catalogue* h_cats, void* workspace,
 	size_t workspace_bytes, const nwayhip_table* h_table, int64_t* d_status, void* stream);
 
