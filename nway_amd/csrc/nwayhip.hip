@@ -37,6 +37,7 @@
 #include "rows.inc"
 #include "finish2.inc"
 #include "tail2.inc"
+#include "tailk.inc"
 #include "elementwise.inc"
 #include "api.inc"
 #include "plan.inc"

@@ -342,6 +342,37 @@ def test_sparse_fast_path_and_its_fallback(nw):
 		np.testing.assert_array_equal(tables[2][key], tables[-1][key], err_msg=key)
 
 
+def test_sparse_fast_path_three_way(nw):
+	"""k = 3 on sparse inputs: the links of a primary stay in fixed slots (no link lists) and are
+	ordered by one small kernel; too many links for the slots -> general path; identical tables"""
+	from nway_amd import _hip
+	rng = np.random.RandomState(33)
+	n0, n1, n2 = 30000, 200000, 150000
+	sky = lambda n: (rng.uniform(0, 360, n), np.degrees(np.arcsin(rng.uniform(-1, 1, n))))
+	a = cat('A', *sky(n0), rng.uniform(0.5, 2, n0), 41252.96)
+	b = cat('B', *sky(n1), 0.3 * np.ones(n1), 41252.96)
+	c = cat('C', *sky(n2), 0.5 * np.ones(n2), 41252.96)
+	for t, m in ((b, 20000), (c, 15000)):
+		t['ra'][:m] = a['ra'][:m] + rng.normal(0, 1, m) / 3600.
+		t['dec'][:m] = np.clip(a['dec'][:m] + rng.normal(0, 1, m) / 3600., -90, 90)
+	# primary 11 gets four counterparts in C, in descending index order of arrival
+	c['ra'][100000:100004] = a['ra'][11]
+	c['dec'][100000:100004] = np.clip(a['dec'][11] + np.arange(4, 0, -1) * 1e-4, -90, 90)
+	tables = {}
+	for slots in (0, 2, -1):
+		res = nw.run_match([a, b, c], 10., 0.9, link_slots=slots, logger=nw.NullOutputLogger())
+		assert int(res.status[_hip.ST_FLAGS]) == 0
+		assert (res.plan.params.link_slots == -1) == (slots != 0)
+		tables[slots] = dict(idx1=res.to_host('idx', 1), idx2=res.to_host('idx', 2), p_i=res.to_host('p_i'),
+			flag=res.to_host('match_flag'), bf=res.to_host('log_bf'), gs=res.plan.cols['group_start'].cpu().numpy())
+		res.plan.close()
+	assert (tables[0]['idx2'] >= 0).sum() > 15000
+	for key in tables[0]:
+		np.testing.assert_array_equal(tables[0][key], tables[-1][key], err_msg=key)
+		np.testing.assert_array_equal(tables[2][key], tables[-1][key], err_msg=key)
+	oracle_vs_hip(nw, [a, b, c], 10., 0.9, ['A', 'B', 'C'], oracle=orc_c)
+
+
 def test_cell_table_overflow_grows_the_table(nw):
 	"""a cell table that is too small for the registrations (sources piled up on a pole need many
 	cells each) is flagged and the run repeated with a larger one: same table as a roomy run"""
