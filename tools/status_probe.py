@@ -77,6 +77,15 @@ cap_pairs, cap_rows = nway_amd._estimate_capacities(sizes, [t['area'] for t in t
 plan, st = _hip.run_plan(sizes, params, cats, cap_pairs, cap_rows, dev)
 print(config, 'scheme', scheme, 'status', [int(x) for x in st[:4]], 'surv', [int(x) for x in st[8:8 + k - 1]],
 	'pairs', [int(x) for x in st[16:16 + k - 1]], 'notflat', [int(x) for x in st[24:24 + k]])
+import time
+for _ in range(3):
+	plan.enqueue(cats)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(20):
+	plan.enqueue(cats)
+torch.cuda.synchronize()
+print('wall (no stage events): %.1f us/step  rows/s=%.3g' % ((time.perf_counter() - t0) / 20 * 1e6, int(st[0]) / ((time.perf_counter() - t0) / 20)))
 plan.profile(0xff)
 reps = 10
 for _ in range(reps):
