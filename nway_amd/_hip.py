@@ -85,6 +85,10 @@ def load():
 	global _lib
 	if _lib is not None:
 		return _lib
+	# PyTorch-ROCm ships its own copy of the HIP runtime: it has to be in the process BEFORE
+	# libnwayhip.so is opened, so that the library binds to that same runtime (opened the other
+	# way round, the process ends up with two runtimes and this one sees no device)
+	torch()
 	path = library_path()
 	if not os.path.exists(path):
 		raise NwayHipError('HIP library %s is not built; run "python -m nway_amd.build" (needs hipcc). '
