@@ -21,6 +21,24 @@ def ratio(hist_sel, hist_all):
 		return numpy.where(hist_all == 0, 100, hist_sel / hist_all)
 
 
+def fraction(bin_mag, hist_sel, hist_all):
+	"""selected / all per bin, rescaled so that its mean over the bins with data (weighted by bin
+	width x "all" density) is 1; bins without data get 1 (magnitudeweights.py:26-42 of the
+	reference, where nothing calls it either)"""
+	bin_mag = numpy.asarray(bin_mag, dtype=float)
+	hist_sel = numpy.asarray(hist_sel, dtype=float)
+	hist_all = numpy.asarray(hist_all, dtype=float)
+	filled = hist_all > 0
+	per_bin = hist_sel[filled] / hist_all[filled]
+	weight = numpy.diff(bin_mag)[filled] * hist_all[filled]
+	mean = (per_bin * weight).sum() / weight.sum()
+	assert mean != 0
+	out = numpy.ones(len(hist_all))
+	out[filled] = per_bin / mean
+	assert numpy.isfinite(out).all() and (out > 0).all(), out
+	return out
+
+
 class StepFunction(object):
 	"""Zero-order interpolant over bin edges, like
 	``interp1d(edges, list(values) + [values[-1]], kind='zero', bounds_error=False)``:

@@ -26,3 +26,12 @@ def test_step_function_matches_interp1d_zero():
 def test_mag_tables_regenerate_exactly():
 	X, O = mag_tables()
 	assert len(O['ra']) == 120000 and np.isnan(O['mags'][0]).sum() == 500
+
+
+def test_fraction_known_answer():
+	"""magnitudeweights.py:26-42 (a helper nothing calls; expected values from the reference run
+	in the build container)"""
+	from nway_amd import magnitudeweights as mw
+	edges = np.array([10, 11, 12.5, 13, 15.])
+	got = mw.fraction(edges, np.array([.1, .5, .3, .1]), np.array([.2, 0, .4, .4]))
+	np.testing.assert_allclose(got, [4 / 3., 1.0, 2.0, 2 / 3.], rtol=1e-14)
