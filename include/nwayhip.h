@@ -85,6 +85,8 @@ typedef struct nwayhip_match_params {
 	int64_t bitmap_bits;                 /* 0 = default; power of two */
 	int64_t table_slots;                 /* cell-table slots (rounded up to a power of two); 0 = default sizing.
 	                                      * NWAYHIP_FLAG_REG_OVERFLOW asks the caller to come back with more. */
+	int64_t f32_roundtrip;               /* 1 = numerics of the script nway.py: separations pass through float32
+	                                      * (FITS 'E' column, fastskymatch.py:328) before being squared in log_bf */
 } nwayhip_match_params;
 
 /* Output table, SoA, `capacity` rows allocated by the caller.  Columns follow

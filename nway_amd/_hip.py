@@ -40,7 +40,8 @@ class MatchParams(ctypes.Structure):
 		('err_deg', ctypes.c_double), ('radius_arcsec', ctypes.c_double), ('prob_ratio_secondary', ctypes.c_double),
 		('dens', ctypes.c_double * MAXCAT), ('dens_plus', ctypes.c_double * MAXCAT),
 		('prior_table', ctypes.c_double * (1 << (MAXCAT - 1))),
-		('sphere_cell_factor', ctypes.c_double), ('bitmap_bits', ctypes.c_int64), ('table_slots', ctypes.c_int64)]
+		('sphere_cell_factor', ctypes.c_double), ('bitmap_bits', ctypes.c_int64), ('table_slots', ctypes.c_int64),
+		('f32_roundtrip', ctypes.c_int64)]
 
 
 class Table(ctypes.Structure):
@@ -277,9 +278,10 @@ class MatchPlan(object):
 
 
 def make_params(ncat, scheme, radius_arcsec, err_deg, dens, dens_plus, prior_table, prob_ratio_secondary=0.5,
-		radius_filter=True, correction=CORRECTION_NONE, finalize=True, sphere_cell_factor=0.0, bitmap_bits=0, link_slots=0, table_slots=0):
+		radius_filter=True, correction=CORRECTION_NONE, finalize=True, sphere_cell_factor=0.0, bitmap_bits=0, link_slots=0, table_slots=0, f32_roundtrip=False):
 	p = MatchParams()
 	p.table_slots = table_slots
+	p.f32_roundtrip = 1 if f32_roundtrip else 0
 	p.link_slots = link_slots
 	p.ncat = ncat
 	p.scheme = scheme

@@ -213,8 +213,12 @@ def main(argv=None):
 		for t, n, rk, dk, e, a in zip(tables, table_names, ra_keys, dec_keys, errors, areas)]
 	print('  computing probabilities ...')
 	correction = _hip.CORRECTION_CLI if (args.consider_unrelated_associations and simple_errors) else _hip.CORRECTION_NONE
-	res = nway_amd.run_match(match_tables, args.radius, completeness, args.acceptable_prob, correction=correction,
-		finalize=(not args.mag) and simple_errors, logger=nway_amd.NullOutputLogger())
+	# the script's numerics: cells from radius / 60 / 60 degrees, the separation filter
+	# against that value * 60 * 60 (fastskymatch.py:336; may differ from --radius in the last bit),
+	# separations squared in float32 after their trip through the FITS 'E' column
+	err_deg = args.radius / 60. / 60
+	res = nway_amd.run_match(match_tables, err_deg * 60 * 60, completeness, args.acceptable_prob, correction=correction,
+		finalize=(not args.mag) and simple_errors, logger=nway_amd.NullOutputLogger(), err_deg=err_deg, f32_roundtrip=True)
 	assert res.nrows > 0, 'No matches.'
 	print('matching: %6d matches after filtering by search radius' % res.nrows)
 	idx_columns = [res.to_host('idx', c).astype(numpy.int64) for c in range(k)]

@@ -46,7 +46,7 @@ def _copy(ptr, n, dtype):
 
 
 def nway_match(match_tables, match_radius, prior_completeness, prob_ratio_secondary=0.5, correction='api',
-		scheme=None, radius_filter=True, err_deg=None):
+		scheme=None, radius_filter=True, err_deg=None, f32_roundtrip=False):
 	"""columns as nway_oracle.nway_match; additionally '_tests' (separation evaluations)"""
 	lib = load()
 	k = len(match_tables)
@@ -69,7 +69,7 @@ def nway_match(match_tables, match_radius, prior_completeness, prob_ratio_second
 	out = Table()
 	rc = lib.nwayo_match(ctypes.c_int(k), arr(ras), arr(decs), arr(sigs), n, ctypes.c_int(scheme), ctypes.c_int(1 if radius_filter else 0),
 		ctypes.c_double(err), ctypes.c_double(match_radius), ptab.ctypes.data_as(dp), dens.ctypes.data_as(dp),
-		dens_plus.ctypes.data_as(dp), ctypes.c_double(prob_ratio_secondary), ctypes.c_int(1 if correction == 'cli' else 0),
+		dens_plus.ctypes.data_as(dp), ctypes.c_double(prob_ratio_secondary), ctypes.c_int((1 if correction == 'cli' else 0) | (2 if f32_roundtrip else 0)),
 		ctypes.byref(out))
 	if rc != 0:
 		raise RuntimeError('nwayo_match failed: %d' % rc)

@@ -511,3 +511,64 @@ def gen_allsky():
 
 if __name__ == '__main__' and ('allsky' in sys.argv[1:] or not sys.argv[1:]):
 	gen_allsky()
+
+
+def script_numerics(tables, radius, completeness, prob_ratio_secondary=0.5):
+	"""The numbers the SCRIPT nway.py would compute, assembled from the reference's
+	own functions: the separations make the trip through a float32 FITS column
+	(fastskymatch.py:328, nway.py:283-302) before _compute_single_log_bf (== nway.py:327-360) and
+	the correction loop of nway.py:366-420 (restated in cli_correction above) see them."""
+	table, resultstable, separations, errors = ref._create_match_table(tables, radius, logger=LOG)
+	sep32 = [[cell.astype(np.float32) if i < j else cell for j, cell in enumerate(row)] for i, row in enumerate(separations)]
+	dens, dens_plus = ref._compute_source_densities(tables, logger=LOG)
+	prior, log_bf = ref._compute_single_log_bf(tables, dens, dens_plus, table, sep32, errors, completeness, logger=LOG)
+	bd = ref.bayesdist
+	ncat = table['ncat'].values
+	ncats = len(tables)
+	prim = resultstable[:, 0]
+	starts = np.flatnonzero(np.r_[True, prim[1:] != prim[:-1]])
+	ends = np.r_[starts[1:], len(prim)]
+	group_of = np.repeat(np.arange(len(starts)), ends - starts)
+	corrected = log_bf.copy()
+	for i in np.where(ncat <= ncats - 2)[0]:
+		missing_cats = [k for k, sep in enumerate(sep32[0]) if np.isnan(sep[i])]
+		best_logpost = 0
+		g = group_of[i]
+		for j in range(starts[g], ends[g]):
+			if not (ncat[j] > 2):
+				continue
+			augmented_cats = [k for k in missing_cats if not np.isnan(sep32[0][k][j])]
+			if len(augmented_cats) >= 2:
+				prior_j = dens[augmented_cats[0]] / np.prod(dens_plus[augmented_cats])
+				errors_selected = [[errors[k][j]] for k in augmented_cats]
+				separations_selected = [[[sep32[k][k2][j]] for k2 in augmented_cats] for k in augmented_cats]
+				log_bf_j = bd.log_bf(np.array(separations_selected), np.array(errors_selected))
+				logpost_j = bd.unnormalised_log_posterior(prior_j, log_bf_j, len(augmented_cats))[0]
+				if logpost_j > best_logpost:
+					best_logpost = logpost_j
+		if best_logpost > 0:
+			corrected[i] += best_logpost
+	table = table.assign(dist_bayesfactor_uncorrected=log_bf, dist_bayesfactor=corrected, dist_post=bd.posterior(prior, corrected))
+	return ref._compute_final_probabilities(tables, table, prob_ratio_secondary, prior, corrected, logger=LOG)
+
+
+def gen_f32():
+	"""edge.npz's 3-way tables (cells straddling Dec = 0) and their first two catalogues with the
+	script's numerics; the inputs are read back from edge.npz"""
+	g = np.load(os.path.join(HERE, 'edge.npz'))
+	tabs = [cat('ABC'[i], g['neg_ra%d' % i], g['neg_dec%d' % i], g['neg_err%d' % i], float(g['neg_area'][0])) for i in range(3)]
+	radius = float(g['neg_radius'][0])
+	out = {}
+	res = script_numerics(tabs, radius, g['neg_completeness'])
+	out.update(table_arrays(res, ['A', 'B', 'C'], 'w3_'))
+	res2 = script_numerics(tabs[:2], radius, g['neg_completeness'][:2])
+	out.update(table_arrays(res2, ['A', 'B'], 'w2_'))
+	api = run(tabs, radius, g['neg_completeness'])
+	out['w3_max_rel_change_of_p_i'] = np.array([np.nanmax(np.abs(res['prob_this_match'].values - api['prob_this_match'].values)
+		/ np.maximum(api['prob_this_match'].values, 1e-300))])
+	print('f32: %d / %d rows; p_i differs from the float64 API by up to %.2e relative' % (len(res), len(res2), out['w3_max_rel_change_of_p_i'][0]))
+	save('f32', **out)
+
+
+if __name__ == '__main__' and ('f32' in sys.argv[1:] or not sys.argv[1:]):
+	gen_f32()

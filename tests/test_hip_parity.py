@@ -159,6 +159,40 @@ def test_edge_cases_golden(nw):
 	assert_table_matches(t, g, 'k4_', ['T0', 'T1', 'T2', 'T3'])
 
 
+def test_script_numerics_golden(nw):
+	"""f32_roundtrip: the numbers of the script nway.py (separations through a float32 FITS column
+	before log_bf and the correction loop), produced with the reference's own
+	functions in tests/golden/make_golden.py: gen_f32; general and sparse-fast paths alike"""
+	g, e = golden('f32'), golden('edge')
+	tabs = [cat('ABC'[i], e['neg_ra%d' % i], e['neg_dec%d' % i], e['neg_err%d' % i], e['neg_area'][0]) for i in range(3)]
+	radius = float(e['neg_radius'][0])
+	t = run(nw, tabs, radius, e['neg_completeness'], unrelated_associations='cli', f32_roundtrip=True)
+	assert_table_matches(t, g, 'w3_', ['A', 'B', 'C'])
+	t = run(nw, tabs[:2], radius, e['neg_completeness'][:2], unrelated_associations='cli', f32_roundtrip=True)
+	assert_table_matches(t, g, 'w2_', ['A', 'B'])
+	# the default (float64, the importable API) is measurably different
+	t64 = run(nw, tabs, radius, e['neg_completeness'], unrelated_associations='cli')
+	assert np.abs(t64['prob_this_match'] - g['w3_prob_this_match']).max() > 1e-7
+	# every row kernel honours the mode: fused sparse tails (k = 2, 3) and general paths
+	rng = np.random.RandomState(35)
+	sky = lambda n: (rng.uniform(0, 360, n), np.degrees(np.arcsin(rng.uniform(-1, 1, n))))
+	a = cat('A', *sky(3000), rng.uniform(0.5, 2, 3000), 41252.96)
+	b = cat('B', *sky(20000), 0.3 * np.ones(20000), 41252.96)
+	c = cat('C', *sky(15000), 0.5 * np.ones(15000), 41252.96)
+	for t_, m in ((b, 2000), (c, 1500)):
+		t_['ra'][:m] = a['ra'][:m] + rng.normal(0, 1, m) / 3600.
+		t_['dec'][:m] = np.clip(a['dec'][:m] + rng.normal(0, 1, m) / 3600., -90, 90)
+	for tabs_ in ([a, b], [a, b, c]):
+		names = [x['name'] for x in tabs_]
+		want = orc_c.nway_match(tabs_, 10., 0.9, f32_roundtrip=True)
+		for slots in (0, -1):
+			res = nw.run_match(tabs_, 10., 0.9, link_slots=slots, f32_roundtrip=True, logger=nw.NullOutputLogger())
+			np.testing.assert_array_equal(res.to_host('idx', len(tabs_) - 1), want[names[-1]])
+			np.testing.assert_allclose(res.to_host('log_bf'), want['dist_bayesfactor'], rtol=RTOL, atol=ATOL)
+			np.testing.assert_allclose(res.to_host('p_i'), want['prob_this_match'], rtol=RTOL, atol=ATOL)
+			res.plan.close()
+
+
 def test_magnitude_priors_golden(nw, tmp_path, monkeypatch):
 	"""__init__.py:304-396: auto histogram by radius, by posterior, user-supplied histogram"""
 	g = golden('mag')
@@ -288,7 +322,7 @@ def test_cli_fits_in_fits_out(nw, tmp_path, monkeypatch):
 	assert out.names == ['CHANDRA_ID', 'CHANDRA_RA', 'CHANDRA_DEC', 'CHANDRA_pos_err', 'OPT_ID', 'OPT_RA', 'OPT_DEC',
 		'Separation_OPT_CHANDRA', 'Separation_max', 'ncat', 'dist_bayesfactor', 'dist_post', 'p_single', 'p_any', 'p_i', 'match_flag']
 	assert out.formats[7:] == ['E', 'E', 'I', 'E', 'E', 'E', 'E', 'E', 'I']
-	api = run(nw, [X, O], 10., 0.9)
+	api = run(nw, [X, O], 10., 0.9, f32_roundtrip=True)  # the script's numerics
 	assert len(out.data) == len(api['ncat']) == 37706
 	np.testing.assert_array_equal(out.data['CHANDRA_ID'], api['CHANDRA'] + 1)
 	np.testing.assert_array_equal(out.data['OPT_ID'], np.where(api['OPT'] >= 0, api['OPT'] + 1, -99))
@@ -301,7 +335,7 @@ def test_cli_fits_in_fits_out(nw, tmp_path, monkeypatch):
 	assert cli.main(['--radius', '10', 'CHANDRA.fits', ':pos_err', 'XMM.fits', ':pos_err', 'OPT.fits', '0.1', '--out', 'out3.fits', '--min-prob', '0.01']) == 0
 	out3 = _fits.read_table('out3.fits')
 	assert 'dist_bayesfactor_corrected' in out3.names and 'Separation_OPT_XMM' in out3.names
-	api3 = run(nw, [X, R, O], 10., 1.0, unrelated_associations='cli', min_prob=0.01)
+	api3 = run(nw, [X, R, O], 10., 1.0, unrelated_associations='cli', min_prob=0.01, f32_roundtrip=True)
 	assert len(out3.data) == len(api3['ncat'])
 	np.testing.assert_array_equal(out3.data['dist_bayesfactor_corrected'], api3['dist_bayesfactor'].astype(np.float32))
 	np.testing.assert_array_equal(out3.data['match_flag'], api3['match_flag'])

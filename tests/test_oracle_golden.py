@@ -11,6 +11,7 @@ from goldenutil import (ROOT, golden, ell_tables, xmm_tables, assert_table_match
 
 sys.path.insert(0, os.path.join(ROOT, 'oracle'))
 import nway_oracle as orc  # noqa: E402
+import nway_oracle_c as orc_c  # noqa: E402
 
 # the oracle repeats the reference's numpy operations in the same order, on the same
 # libm: it is expected to agree far below the product tolerance
@@ -191,3 +192,22 @@ def test_sphere_scheme_equals_bruteforce():
 	expect = np.array(sorted(expect))
 	np.testing.assert_array_equal(rows, expect)
 	assert (rows[:, 1] >= 0).sum() > 50 and ((rows[:, 1] >= 0) & (rows[:, 2] >= 0)).sum() > 10
+
+
+def test_script_numerics_float32_round_trip():
+	"""nway.py reads the separations back from a float32 FITS column before log_bf
+	squares them and before its correction loop; tests/golden/f32.npz holds what the reference's
+	own functions give on such separations (p_i moves by up to 3e-5 relative: far outside the
+	1e-6 contract, so the script's numerics are a mode of their own)"""
+	g, e = golden('f32'), golden('edge')
+	tabs = [cat('ABC'[i], e['neg_ra%d' % i], e['neg_dec%d' % i], e['neg_err%d' % i], e['neg_area'][0]) for i in range(3)]
+	radius = float(e['neg_radius'][0])
+	for oracle in (orc, orc_c):
+		kw = dict(literal_groups=True) if oracle is orc else {}
+		t = oracle.nway_match(tabs, radius, e['neg_completeness'], correction='cli', f32_roundtrip=True, **kw)
+		assert_table_matches(t, g, 'w3_', ['A', 'B', 'C'], **TIGHT)
+		t = oracle.nway_match(tabs[:2], radius, e['neg_completeness'][:2], correction='cli', f32_roundtrip=True, **kw)
+		assert_table_matches(t, g, 'w2_', ['A', 'B'], **TIGHT)
+	assert g['w3_max_rel_change_of_p_i'][0] > 1e-6
+	api = orc.nway_match(tabs, radius, e['neg_completeness'], correction='cli')
+	assert np.abs(api['prob_this_match'] - g['w3_prob_this_match']).max() > 1e-7
