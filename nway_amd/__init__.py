@@ -221,6 +221,8 @@ def nway_match(match_tables, match_radius, prior_completeness,
 	has_mags = any(len(t.get('mags', [])) > 0 for t in match_tables)
 	correction = _hip.CORRECTION_CLI if (consider_unrelated_associations and unrelated_associations == 'cli') else _hip.CORRECTION_NONE
 
+	if len(match_tables[0]['ra']) == 0:
+		raise EmptyResultException('No matches.')  # nothing can create a bucket (fastskymatch.py:131)
 	logger.log('Computing distance-based probabilities ...')
 	res = run_match(match_tables, match_radius, prior_completeness, prob_ratio_secondary,
 		correction=correction, finalize=not has_mags, device=device, logger=logger, f32_roundtrip=f32_roundtrip)

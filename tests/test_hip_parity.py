@@ -222,6 +222,9 @@ def test_empty_secondary_catalogue(nw):
 	t = run(nw, [tp, ts], 5., 0.9)
 	# a primary always keeps its no-counterpart row: one row, flagged 1
 	assert len(t['ncat']) == 1 and t['match_flag'][0] == 1 and t['prob_has_match'][0] == 0
+	# no primaries: nothing creates a bucket (fastskymatch.py:131) -> the reference's "No matches."
+	with pytest.raises(nw.EmptyResultException):
+		run(nw, [ts, tp], 5., 0.9)
 
 
 def oracle_vs_hip(nw, tabs, radius, completeness, names, oracle=orc, **kw):
