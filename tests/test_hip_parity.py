@@ -410,6 +410,35 @@ def test_sparse_fast_path_three_way(nw):
 	oracle_vs_hip(nw, [a, b, c], 10., 0.9, ['A', 'B', 'C'], oracle=orc_c)
 
 
+@pytest.mark.parametrize('k,slots', [(2, 0), (3, 0), (2, -1), (3, -1)])
+def test_repeated_runs_of_one_plan(nw, k, slots):
+	"""a plan is enqueued again and again on its workspace (the bench's step): the epoch-tagged
+	cell table is never cleared, the sparse paths alternate between two scratch copies and zero
+	the status block from k_register -- every run must give the same table and status words"""
+	from nway_amd import _hip
+	rng = np.random.RandomState(36)
+	sky = lambda n: (rng.uniform(0, 360, n), np.degrees(np.arcsin(rng.uniform(-1, 1, n))))
+	a = cat('A', *sky(20000), rng.uniform(0.5, 2, 20000), 41252.96)
+	b = cat('B', *sky(150000), 0.3 * np.ones(150000), 41252.96)
+	c = cat('C', *sky(100000), 0.5 * np.ones(100000), 41252.96)
+	for t_, m in ((b, 15000), (c, 10000)):
+		t_['ra'][:m] = a['ra'][:m] + rng.normal(0, 1, m) / 3600.
+		t_['dec'][:m] = np.clip(a['dec'][:m] + rng.normal(0, 1, m) / 3600., -90, 90)
+	tabs = [a, b, c][:k]
+	res = nw.run_match(tabs, 10., 0.9, link_slots=slots, logger=nw.NullOutputLogger())
+	snap = lambda: dict(status=res.plan.read_status().copy(), idx=res.plan.cols['idx'][k - 1][:res.nrows].cpu().numpy().copy(),
+		p_i=res.plan.cols['p_i'][:res.nrows].cpu().numpy().copy(), flag=res.plan.cols['match_flag'][:res.nrows].cpu().numpy().copy())
+	first = snap()
+	assert first['status'][_hip.ST_FLAGS] == 0 and first['status'][_hip.ST_ROWS] == res.nrows
+	cats = [_hip.DeviceCatalogue(t['ra'], t['dec'], np.asarray(t['error'], dtype=float), res.plan.device) for t in tabs]
+	for _ in range(5):
+		res.plan.enqueue(cats)
+		again = snap()
+		for key in first:
+			np.testing.assert_array_equal(again[key], first[key], err_msg=key)
+	res.plan.close()
+
+
 def test_cell_table_overflow_grows_the_table(nw):
 	"""a cell table that is too small for the registrations (sources piled up on a pole need many
 	cells each) is flagged and the run repeated with a larger one: same table as a roomy run"""
