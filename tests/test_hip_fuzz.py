@@ -17,11 +17,11 @@ pytestmark = pytest.mark.gpu
 FLOATS = ('Separation_max', 'dist_bayesfactor_uncorrected', 'dist_bayesfactor', 'dist_post', 'p_single', 'prob_has_match', 'prob_this_match')
 
 
-def compare(nw, tabs, radius, completeness, correction):
+def compare(nw, tabs, radius, completeness, correction, f32=False):
 	names = [t['name'] for t in tabs]
-	want = orc.nway_match(tabs, radius, completeness, correction=correction, literal_groups=True)
+	want = orc.nway_match(tabs, radius, completeness, correction=correction, literal_groups=True, f32_roundtrip=f32)
 	got = nw.nway_match(tabs, radius, completeness, logger=nw.NullOutputLogger(),
-		unrelated_associations='cli' if correction == 'cli' else 'api')
+		unrelated_associations='cli' if correction == 'cli' else 'api', f32_roundtrip=f32)
 	assert len(got) == len(want['ncat']), (len(got), len(want['ncat']))
 	for n in names:
 		np.testing.assert_array_equal(got[n].values, want[n])
@@ -100,5 +100,40 @@ def test_random_configurations(seed):
 	if seed % 2 == 1 and k > 4:
 		tabs = tabs[:4]
 	comp = float(rng.choice([1.0, 0.9, 0.5]))
-	rows = compare(nw, tabs, radius, comp, 'cli' if seed % 3 == 0 else 'api')
+	# every fifth configuration with the script's float32 numerics
+	rows = compare(nw, tabs, radius, comp, 'cli' if seed % 3 == 0 else 'api', f32=(seed % 5 == 0))
 	assert rows >= len(tabs[0]['ra'])
+
+
+@pytest.mark.parametrize('k', [6, 7, 8])
+@pytest.mark.parametrize('kind', ['flat', 'sphere'])
+def test_many_catalogues(k, kind):
+	"""up to the 8 catalogues the ABI allows: the breadth-first path (dense flat patch) and the
+	fused sparse tail k_tailk<6..8> (a few isolated clumps on the whole sky)"""
+	import nway_amd as nw
+	rng = np.random.default_rng(77 + k)
+	radius = 20.0
+	if kind == 'flat':
+		tabs = []
+		for c in range(k):
+			n = 6 if c == 0 else int(rng.integers(3, 9))
+			tabs.append(cat('T%d' % c, 150 + rng.uniform(0, 0.02, n), 2 + rng.uniform(0, 0.02, n), rng.uniform(1, 5, n), 4e-4))
+	else:
+		n0 = 40
+		ra0, dec0 = rng.uniform(0, 360, n0), np.degrees(np.arcsin(rng.uniform(-1, 1, n0)))
+		dec0[0], dec0[1] = 89.9999, -89.9999
+		tabs = [cat('T0', ra0, dec0, rng.uniform(1, 3, n0), 41252.96)]
+		for c in range(1, k):
+			keep = rng.random(n0) < 0.7
+			ra = ra0[keep] + rng.normal(0, 2, keep.sum()) / 3600. / np.maximum(np.cos(np.radians(dec0[keep])), 1e-3)
+			dec = np.clip(dec0[keep] + rng.normal(0, 2, keep.sum()) / 3600., -90, 90)
+			extra = int(rng.integers(0, 30))
+			ra = np.concatenate([ra % 360, rng.uniform(0, 360, extra)])
+			dec = np.concatenate([dec, np.degrees(np.arcsin(rng.uniform(-1, 1, extra)))])
+			tabs.append(cat('T%d' % c, ra, dec, 1.5 * np.ones(len(ra)), 41252.96))
+	rows = compare(nw, tabs, radius, 0.8, 'api')
+	assert rows >= len(tabs[0]['ra'])
+	res = nw.run_match(tabs, radius, 0.8, logger=nw.NullOutputLogger())
+	if kind == 'sphere':
+		assert res.plan.params.link_slots == 0  # stayed on the sparse path
+	res.plan.close()
