@@ -70,9 +70,11 @@ typedef struct nwayhip_match_params {
 	int32_t correction;                  /* NWAYHIP_CORRECTION_* */
 	int32_t finalize;                    /* 1: also run the per-primary group statistics with
 	                                        total = dist_bayesfactor (no magnitude biases) */
-	int32_t link_slots;                  /* 2-catalogue sparse fast path: links kept in this many fixed slots
-	                                        per primary and the tail fused into one launch.  0 = decide from
-	                                        the densities, -1 = never, > 0 = force that many slots */
+	int32_t link_slots;                  /* sparse fast path (any number of catalogues): the links of every
+	                                        secondary catalogue are kept in this many fixed slots per primary
+	                                        and everything after them is fused into one launch.  0 = decide
+	                                        from the densities (8 slots if every catalogue expects < 0.5
+	                                        chance neighbours per primary), -1 = never, > 0 = force */
 	double err_deg;                      /* cell size: match_radius / 60. / 60 (__init__.py:128) */
 	double radius_arcsec;                /* match_radius */
 	double prob_ratio_secondary;         /* __init__.py:33 */
