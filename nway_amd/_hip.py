@@ -326,7 +326,10 @@ def run_plan(sizes, params, catalogues, cap_pairs, cap_rows, device, max_retries
 			continue
 		if flags & (FLAG_PAIR_OVERFLOW | FLAG_ROW_OVERFLOW):
 			need_pairs = int(max(st[ST_PAIRS:ST_PAIRS + 8]))
-			cap_pairs = max(cap_pairs, int(need_pairs * 1.05) + 1024)
+			grown = max(cap_pairs, int(need_pairs * 1.05) + 1024)
+			if flags & FLAG_PAIR_OVERFLOW and grown == cap_pairs:
+				grown = cap_pairs * 2  # the total fits but one workgroup's region of the link arrays did not
+			cap_pairs = grown
 			if flags & FLAG_ROW_OVERFLOW and not flags & FLAG_PAIR_OVERFLOW:
 				cap_rows = max(cap_rows * 2, int(st[ST_ROWS] * 1.05) + 1024)
 			elif flags & FLAG_ROW_OVERFLOW:
