@@ -44,6 +44,8 @@ extern "C" {
 #define NWAYHIP_ST_FLAGS 1               /* bit mask, NWAYHIP_FLAG_* */
 #define NWAYHIP_ST_REGISTRATIONS 2       /* primary -> cell registrations */
 #define NWAYHIP_ST_TESTS 3               /* great-circle distance tests executed (M0') */
+#define NWAYHIP_ST_REGION_NEED 4         /* with NWAYHIP_FLAG_PAIR_OVERFLOW: links one workgroup wanted to keep, if that
+                                            (and not the total) is what did not fit: come back with link_region_min */
 #define NWAYHIP_ST_SURVIVORS 8           /* + c: secondaries of catalogue c passing the cell filter */
 #define NWAYHIP_ST_PAIRS 16              /* + c: (primary, secondary) links of catalogue c */
 #define NWAYHIP_ST_NOTFLAT 24            /* + c: 1 if catalogue c violates the flat-cell condition */
@@ -87,6 +89,8 @@ typedef struct nwayhip_match_params {
 	int64_t bitmap_bits;                 /* 0 = default; power of two */
 	int64_t table_slots;                 /* cell-table slots (rounded up to a power of two); 0 = default sizing.
 	                                      * NWAYHIP_FLAG_REG_OVERFLOW asks the caller to come back with more. */
+	int64_t link_region_min;             /* general path: least number of links every workgroup of the pairs kernels can
+	                                      * keep (0 = derived from cap_pairs); see NWAYHIP_ST_REGION_NEED */
 	int64_t f32_roundtrip;               /* 1 = numerics of the script nway.py: separations pass through float32
 	                                      * (FITS 'E' column, fastskymatch.py:328) before being squared in log_bf */
 } nwayhip_match_params;

@@ -16,7 +16,7 @@ from . import build as _build
 MAXCAT = 8
 MAXPAIR = 28
 STATUS_WORDS = 32
-ST_ROWS, ST_FLAGS, ST_REGISTRATIONS, ST_TESTS = 0, 1, 2, 3
+ST_ROWS, ST_FLAGS, ST_REGISTRATIONS, ST_TESTS, ST_REGION_NEED = 0, 1, 2, 3, 4
 ST_SURVIVORS, ST_PAIRS, ST_NOTFLAT = 8, 16, 24
 FLAG_PAIR_OVERFLOW, FLAG_ROW_OVERFLOW, FLAG_REG_OVERFLOW, FLAG_SLOT_OVERFLOW, FLAG_LOOKBACK = 1, 2, 4, 8, 16
 SCHEME_FLAT, SCHEME_SPHERE = 0, 1
@@ -41,7 +41,7 @@ class MatchParams(ctypes.Structure):
 		('dens', ctypes.c_double * MAXCAT), ('dens_plus', ctypes.c_double * MAXCAT),
 		('prior_table', ctypes.c_double * (1 << (MAXCAT - 1))),
 		('sphere_cell_factor', ctypes.c_double), ('bitmap_bits', ctypes.c_int64), ('table_slots', ctypes.c_int64),
-		('f32_roundtrip', ctypes.c_int64)]
+		('link_region_min', ctypes.c_int64), ('f32_roundtrip', ctypes.c_int64)]
 
 
 class Table(ctypes.Structure):
@@ -326,10 +326,10 @@ def run_plan(sizes, params, catalogues, cap_pairs, cap_rows, device, max_retries
 			continue
 		if flags & (FLAG_PAIR_OVERFLOW | FLAG_ROW_OVERFLOW):
 			need_pairs = int(max(st[ST_PAIRS:ST_PAIRS + 8]))
-			grown = max(cap_pairs, int(need_pairs * 1.05) + 1024)
-			if flags & FLAG_PAIR_OVERFLOW and grown == cap_pairs:
-				grown = cap_pairs * 2  # the total fits but one workgroup's region of the link arrays did not
-			cap_pairs = grown
+			cap_pairs = max(cap_pairs, int(need_pairs * 1.05) + 1024)
+			if flags & FLAG_PAIR_OVERFLOW and int(st[ST_REGION_NEED]) > 0:
+				# the total may fit, but one workgroup's region of the link arrays did not (clustered input)
+				params.link_region_min = max(int(params.link_region_min), int(int(st[ST_REGION_NEED]) * 1.3) + 64)
 			if flags & FLAG_ROW_OVERFLOW and not flags & FLAG_PAIR_OVERFLOW:
 				cap_rows = max(cap_rows * 2, int(st[ST_ROWS] * 1.05) + 1024)
 			elif flags & FLAG_ROW_OVERFLOW:
