@@ -17,6 +17,7 @@
 // reference's numpy expressions (only libm differs: ocml vs glibc, <= 1-2 ulp).
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <cmath>
 #include <cstdarg>
