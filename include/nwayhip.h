@@ -156,7 +156,8 @@ int nwayhip_match_enqueue(nwayhip_plan* plan, const nwayhip_catalogue* h_cats, v
 
 /* Stage timing with HIP events recorded on the pipeline's own stream (bench.py's roofline leg).
  * stage_mask: bit s set => every launch group of stage s in subsequent nwayhip_match_enqueue
- * calls is bracketed by an event pair (ring of NWAYHIP_PROFILE_RING pairs per stage).
+ * calls is bracketed by an event pair (ring of NWAYHIP_PROFILE_RING pairs per stage); the
+ * sweep, a single launch, carries its pair on its own dispatch (kernel begin / end timestamps).
  * nwayhip_plan_profile_read waits for the recorded events, returns per stage the number of
  * bracketed launch groups and their summed duration in ms, and resets the counters. */
 #define NWAYHIP_STAGE_REGISTER 0
