@@ -222,6 +222,18 @@ def test_empty_secondary_catalogue(nw):
 	t = run(nw, [tp, ts], 5., 0.9)
 	# a primary always keeps its no-counterpart row: one row, flagged 1
 	assert len(t['ncat']) == 1 and t['match_flag'][0] == 1 and t['prob_has_match'][0] == 0
+	# sparse 3- and 4-way with an empty and a one-source catalogue among the secondaries (all of
+	# them share one sweep launch: every catalogue must get its workgroups)
+	rng = np.random.RandomState(37)
+	sky = lambda n: (rng.uniform(0, 360, n), np.degrees(np.arcsin(rng.uniform(-1, 1, n))))
+	a = cat('A', *sky(2000), rng.uniform(0.5, 2, 2000), 41252.96)
+	b = cat('B', *sky(30000), 0.3 * np.ones(30000), 41252.96)
+	b['ra'][:1500] = a['ra'][:1500] + rng.normal(0, 1, 1500) / 3600.
+	b['dec'][:1500] = np.clip(a['dec'][:1500] + rng.normal(0, 1, 1500) / 3600., -90, 90)
+	empty = cat('E', np.zeros(0), np.zeros(0), np.zeros(0), 41252.96)
+	one = cat('O', a['ra'][:1] + 1e-4, a['dec'][:1], np.array([0.5]), 41252.96)
+	oracle_vs_hip(nw, [a, b, empty], 10., 0.9, ['A', 'B', 'E'], oracle=orc_c)
+	oracle_vs_hip(nw, [a, empty, b, one], 10., 0.9, ['A', 'E', 'B', 'O'], oracle=orc_c)
 	# no primaries: nothing creates a bucket (fastskymatch.py:131) -> the reference's "No matches."
 	with pytest.raises(nw.EmptyResultException):
 		run(nw, [ts, tp], 5., 0.9)
