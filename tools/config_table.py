@@ -17,6 +17,7 @@ CONFIGS = [
 	('C4-S 3-way 1e5 x 1e6 x 1e6, uniform sky, 10"', ['c4s'], 3, [100000, 1000000, 1000000]),
 	('C4-D 3-way 1e5 x 1e6 x 1e6, 8 deg^2 patch, 10"', ['c4d'], 3, [100000, 1000000, 1000000]),
 	('C5 shard (1 of 8 GPUs) 2-way 62500 x 1e8, uniform sky, 5"', ['c3s', '62500', '100000000'], 2, [62500, 100000000]),
+	('C5 whole on ONE GPU 2-way 5e5 x 1e8, uniform sky, 5"', ['c3s', '500000', '100000000'], 2, [500000, 100000000]),
 ]
 print('| configuration | rows M | distance tests | us per pass | rows/s | B_alg (MB) | B_alg / t (GB/s) | of 8 TB/s |')
 print('|---|---|---|---|---|---|---|---|')
