@@ -67,16 +67,18 @@ def fitfunc_histogram(bin_mag, hist_sel, hist_all):
 
 
 def _linear_interpolant(x, y, x_new):
-	"""piecewise-linear y(x_new) for sorted x (what interp1d(x, y) evaluates): the segment is
-	found with searchsorted and clipped to the first/last one"""
+	"""piecewise-linear y(x_new) exactly as ``interp1d(x, y)`` evaluates it for 1-D float data:
+	scipy first orders the knots by x with a stable sort (``assume_sorted=False``) and then hands
+	the evaluation to ``numpy.interp``.  Both steps matter for the cumulative weight axis of
+	``adaptive_histograms``: a running sum divided by the total can exceed 1 by an ulp just before
+	the last knot (which is set to exactly 1), so the knots are NOT sorted, and weights that
+	are 0 (or lost to rounding) repeat knots, of which numpy.interp takes the last.  A plain
+	searchsorted restatement moved the uppermost bin border of one magnitude column of a 3-way
+	match and, through it, one match_flag of 62 960."""
 	x = numpy.asarray(x, dtype=float)
 	y = numpy.asarray(y, dtype=float)
-	x_new = numpy.asarray(x_new, dtype=float)
-	hi = numpy.clip(numpy.searchsorted(x, x_new), 1, len(x) - 1)
-	lo = hi - 1
-	with numpy.errstate(divide='ignore', invalid='ignore'):
-		slope = (y[hi] - y[lo]) / (x[hi] - x[lo])
-		return slope * (x_new - x[lo]) + y[lo]
+	order = numpy.argsort(x, kind='mergesort')
+	return numpy.interp(numpy.asarray(x_new, dtype=float), x[order], y[order])
 
 
 def adaptive_histograms(mag_all, mag_sel, weights=None):

@@ -572,3 +572,95 @@ def gen_f32():
 
 if __name__ == '__main__' and ('f32' in sys.argv[1:] or not sys.argv[1:]):
 	gen_f32()
+
+
+def mag3_catalogues(xmm_ra, xmm_dec, seed, n_opt, n_irac, k_opt, k_irac):
+	"""seeded OPT / IRAC stand-ins with magnitude columns (two in OPT, one in IRAC) in which the
+	true counterparts of the first XMM sources are brighter.  tests/goldenutil.py:mag3_tables
+	repeats this recipe; keep them identical."""
+	rng = np.random.RandomState(seed)
+	cols = {}
+	for name, n, k, sig, m0 in (('OPT', n_opt, k_opt, 0.3, 24.0), ('IRAC', n_irac, k_irac, 0.6, 22.5)):
+		ra = rng.uniform(149.35, 150.87, size=n)
+		dec = rng.uniform(1.47, 2.96, size=n)
+		mag = rng.normal(m0, 1.5, size=n)
+		slots = rng.choice(n, size=k, replace=False)
+		ra[slots] = xmm_ra[:k] + rng.normal(0, sig, size=k) / 3600. / np.cos(np.radians(xmm_dec[:k]))
+		dec[slots] = xmm_dec[:k] + rng.normal(0, sig, size=k) / 3600.
+		mag[slots] = rng.normal(m0 - 3.0, 1.0, size=k)
+		mag[rng.choice(n, size=n // 50, replace=False)] = -99
+		mag[rng.choice(n, size=n // 300, replace=False)] = np.nan
+		cols[name] = [ra, dec, mag]
+		if name == 'OPT':
+			colour = mag + rng.normal(0.0, 0.7, size=n)  # a second, correlated band
+			colour[slots] -= 0.8
+			colour[~np.isfinite(mag) | (mag == -99)] = -99
+			cols[name].append(colour)
+	return cols
+
+
+def gen_mag3():
+	"""BASELINE configs[1] in shape: XMM x OPT x IRAC with magnitude priors learned from the data
+	(posterior-selected, the default), three magnitude columns over two catalogues"""
+	XMM = _fits.read_table(os.path.join(REFERENCE, 'doc/COSMOS_XMM.fits'))
+	d = XMM.data
+	seed, n_opt, n_irac, k_opt, k_irac = 91, 150000, 90000, 1500, 1300
+	cols = mag3_catalogues(d['RA'], d['DEC'], seed, n_opt, n_irac, k_opt, k_irac)
+	tX = cat('XMM', d['RA'], d['DEC'], d['pos_err'].astype(float), 2.0)
+	tO = cat('OPT', cols['OPT'][0], cols['OPT'][1], 0.1 * np.ones(n_opt), 2.0)
+	tO['mags'], tO['magnames'], tO['maghists'] = [cols['OPT'][2].copy(), cols['OPT'][3].copy()], ['R', 'I'], [None, None]
+	tI = cat('IRAC', cols['IRAC'][0], cols['IRAC'][1], 0.5 * np.ones(n_irac), 2.0)
+	tI['mags'], tI['magnames'], tI['maghists'] = [cols['IRAC'][2].copy()], ['CH1'], [None]
+	out = dict(seed=np.array([seed]), sizes=np.array([n_opt, n_irac, k_opt, k_irac]),
+		checksum=np.array([cols['OPT'][0].sum(), cols['OPT'][1].sum(), np.nansum(cols['OPT'][2]), np.nansum(cols['OPT'][3]),
+			cols['IRAC'][0].sum(), cols['IRAC'][1].sum(), np.nansum(cols['IRAC'][2])]))
+	names = ['XMM', 'OPT', 'IRAC']
+	biases = ['bias_OPT_R', 'bias_OPT_I', 'bias_IRAC_CH1']
+	cwd = os.getcwd()
+	import tempfile
+	os.chdir(tempfile.mkdtemp(prefix='nwaymag3_'))
+	try:
+		res = ref.nway_match([tX, tO, tI], match_radius=20., prior_completeness=0.9, store_mag_hists=False, logger=LOG)
+	finally:
+		os.chdir(cwd)
+	out.update(checksums(res, names, 'm3_'))
+	out.update(subset_rows(res, names, 23, 'm3_'))
+	mask = (res['XMM'].values % 23) == 0
+	for b in biases:
+		v = res[b].values
+		out['m3_sum_' + b] = np.array([v.sum()])
+		out['m3_sub_' + b] = v[mask]
+	# adaptive_histograms with weights that are exactly zero (repeated knots in the cumulative
+	# weight axis): which knot supplies a quantile is scipy's / numpy.interp's choice
+	rng = np.random.RandomState(5)
+	a = rng.normal(22, 2, size=3000)
+	s = rng.normal(20, 1, size=200)
+	w = rng.randint(1, 65, size=200) / 64.  # sums are exact: the repeated knots are bit-equal
+	order = np.argsort(s)
+	w[order[-3:]] = 0.0   # the brightest-weight tail carries no weight: the last knots repeat
+	w[order[:2]] = 0.0    # ... and the first ones
+	w[order[90:95]] = 0.0  # ... and a run in the middle
+	bins, hs, ha = ref.magnitudeweights.adaptive_histograms(a, s, weights=w)
+	out['ah0_all'], out['ah0_sel'], out['ah0_w'] = a, s, w
+	out['ah0_bins'], out['ah0_hist_sel'], out['ah0_hist_all'] = bins, hs, ha
+	# ... and the IRAC column's own selection from the run above: its running weight sum exceeds the
+	# total by an ulp just before the last knot, i.e. the knots interp1d receives are not sorted
+	idx = res['IRAC'].values
+	defined = idx != -1
+	post = res['dist_post'].values
+	rows, first = np.unique(idx[(post > 0.9) & defined], return_index=True)
+	wsel = post[defined][first]
+	msel = tI['mags'][0][rows]
+	ok = np.isfinite(msel)
+	a1 = tI['mags'][0][np.isfinite(tI['mags'][0])][::150]
+	c1 = np.cumsum(wsel[ok][np.argsort(msel[ok])]) / np.sum(wsel[ok])
+	assert (np.diff(np.r_[c1[:-1], 1.0]) < 0).any(), 'the fixture no longer has unsorted knots'
+	bins, hs, ha = ref.magnitudeweights.adaptive_histograms(a1, msel[ok], weights=wsel[ok])
+	out['ah1_all'], out['ah1_sel'], out['ah1_w'] = a1, msel[ok], wsel[ok]
+	out['ah1_bins'], out['ah1_hist_sel'], out['ah1_hist_all'] = bins, hs, ha
+	print('mag3: %d rows, flags %s, bias sums %s' % (len(res), np.bincount(res['match_flag'].values), [float(out['m3_sum_' + b][0]) for b in biases]))
+	save('mag3', **out)
+
+
+if __name__ == '__main__' and ('mag3' in sys.argv[1:] or not sys.argv[1:]):
+	gen_mag3()

@@ -72,6 +72,40 @@ def mag_tables(maghist=None):
 	return [X, O]
 
 
+def mag3_tables():
+	"""XMM x OPT x IRAC stand-ins with three magnitude columns (recipe of
+	make_golden.py:mag3_catalogues; the shape of BASELINE configs[1])"""
+	g = golden('xmm_inputs')
+	m = golden('mag3')
+	n_opt, n_irac, k_opt, k_irac = [int(v) for v in m['sizes']]
+	rng = np.random.RandomState(int(m['seed'][0]))
+	cols = {}
+	for name, n, k, sig, m0 in (('OPT', n_opt, k_opt, 0.3, 24.0), ('IRAC', n_irac, k_irac, 0.6, 22.5)):
+		ra = rng.uniform(149.35, 150.87, size=n)
+		dec = rng.uniform(1.47, 2.96, size=n)
+		mag = rng.normal(m0, 1.5, size=n)
+		slots = rng.choice(n, size=k, replace=False)
+		ra[slots] = g['RA'][:k] + rng.normal(0, sig, size=k) / 3600. / np.cos(np.radians(g['DEC'][:k]))
+		dec[slots] = g['DEC'][:k] + rng.normal(0, sig, size=k) / 3600.
+		mag[slots] = rng.normal(m0 - 3.0, 1.0, size=k)
+		mag[rng.choice(n, size=n // 50, replace=False)] = -99
+		mag[rng.choice(n, size=n // 300, replace=False)] = np.nan
+		cols[name] = [ra, dec, mag]
+		if name == 'OPT':
+			colour = mag + rng.normal(0.0, 0.7, size=n)
+			colour[slots] -= 0.8
+			colour[~np.isfinite(mag) | (mag == -99)] = -99
+			cols[name].append(colour)
+	np.testing.assert_allclose([cols['OPT'][0].sum(), cols['OPT'][1].sum(), np.nansum(cols['OPT'][2]), np.nansum(cols['OPT'][3]),
+		cols['IRAC'][0].sum(), cols['IRAC'][1].sum(), np.nansum(cols['IRAC'][2])], m['checksum'], rtol=0, atol=0)
+	X = cat('XMM', g['RA'], g['DEC'], g['pos_err'].astype(float), 2.0)
+	O = cat('OPT', cols['OPT'][0], cols['OPT'][1], 0.1 * np.ones(n_opt), 2.0)
+	O['mags'], O['magnames'], O['maghists'] = [cols['OPT'][2], cols['OPT'][3]], ['R', 'I'], [None, None]
+	I = cat('IRAC', cols['IRAC'][0], cols['IRAC'][1], 0.5 * np.ones(n_irac), 2.0)
+	I['mags'], I['magnames'], I['maghists'] = [cols['IRAC'][2]], ['CH1'], [None]
+	return [X, O, I]
+
+
 def idx_hash(idx):
 	idx = np.asarray(idx).astype(np.int64)
 	w = np.arange(1, len(idx) + 1, dtype=np.uint64)

@@ -216,6 +216,22 @@ def test_magnitude_priors_golden(nw, tmp_path, monkeypatch):
 		run(nw, few, 20., 0.9, store_mag_hists=False, mag_include_radius=4.0)
 
 
+def test_three_way_magnitude_priors_golden(nw, tmp_path, monkeypatch):
+	"""the shape of BASELINE configs[1]: XMM x OPT x IRAC with magnitude priors learned from the
+	data (posterior-selected), three magnitude columns over two catalogues"""
+	from goldenutil import mag3_tables
+	g = golden('mag3')
+	monkeypatch.chdir(tmp_path)
+	names = ['XMM', 'OPT', 'IRAC']
+	t = run(nw, mag3_tables(), 20., 0.9, store_mag_hists=False)
+	assert_checksums_match(t, g, 'm3_', names)
+	rows = g['m3_sub_rows']
+	assert_table_matches(t, g, 'm3_sub_', names, rows=rows)
+	for b in ('bias_OPT_R', 'bias_OPT_I', 'bias_IRAC_CH1'):
+		np.testing.assert_allclose(np.asarray(t[b])[rows], g['m3_sub_' + b], rtol=RTOL, err_msg=b)
+		np.testing.assert_allclose(np.sum(t[b]), g['m3_sum_' + b][0], rtol=1e-9, err_msg=b)
+
+
 def test_empty_secondary_catalogue(nw):
 	tp = cat('P', [10.0], [10.0], [1.0], 1.0)
 	ts = cat('S', np.zeros(0), np.zeros(0), np.zeros(0), 1.0)

@@ -23,6 +23,26 @@ def test_step_function_matches_interp1d_zero():
 	np.testing.assert_array_equal(mw.ratio([1., 2., 0.], [2., 0., 0.]), [0.5, 100., 100.])
 
 
+def test_adaptive_histograms_with_zero_weights():
+	"""repeated knots in the cumulative weight axis (weights that are exactly 0): the quantile
+	borders follow numpy.interp, which scipy's interp1d delegates to"""
+	from nway_amd import magnitudeweights as mw
+	g = golden('mag3')
+	# ah1: a real selection whose running weight sum passes the total by an ulp before the last
+	# knot -- interp1d sorts its knots before evaluating
+	for case in ('ah0', 'ah1'):
+		bins, hs, ha = mw.adaptive_histograms(g[case + '_all'], g[case + '_sel'], weights=g[case + '_w'])
+		np.testing.assert_array_equal(bins, g[case + '_bins'])
+		np.testing.assert_allclose(hs, g[case + '_hist_sel'], rtol=1e-13)
+		np.testing.assert_allclose(ha, g[case + '_hist_all'], rtol=1e-13)
+
+
+def test_mag3_tables_regenerate_exactly():
+	from goldenutil import mag3_tables
+	X, O, I = mag3_tables()  # asserts the stored checksums
+	assert len(O['mags']) == 2 and len(I['mags']) == 1
+
+
 def test_mag_tables_regenerate_exactly():
 	X, O = mag_tables()
 	assert len(O['ra']) == 120000 and np.isnan(O['mags'][0]).sum() == 500
