@@ -664,3 +664,30 @@ def gen_mag3():
 
 if __name__ == '__main__' and ('mag3' in sys.argv[1:] or not sys.argv[1:]):
 	gen_mag3()
+
+
+def gen_kway():
+	"""4- and 5-way matches on small clustered tables: the generic-k enumeration, the 2^(k-1)
+	presence patterns of the Bayes factor / prior, and the script's unrelated-association correction
+	for k > 3 (rows with ncat <= k - 2 augmented by two or more of their missing catalogues)"""
+	out = {}
+	for tag, sizes, radius, comp, seed in (('k4c', (25, 160, 140, 120), 25., 0.7, 11), ('k5', (12, 25, 22, 20, 18), 20., np.array([1.0, 0.9, 0.8, 0.7, 0.6]), 19)):
+		rng = np.random.RandomState(seed)
+		span = 0.05 if tag == 'k4c' else 0.02
+		tabs = []
+		for i, n in enumerate(sizes):
+			ra = rng.uniform(200.0, 200.0 + span, size=n)
+			dec = rng.uniform(30.0, 30.0 + span, size=n)
+			tabs.append(cat('T%d' % i, ra, dec, rng.uniform(0.5, 3., size=n), span**2))
+			out['%s_ra%d' % (tag, i)], out['%s_dec%d' % (tag, i)], out['%s_err%d' % (tag, i)] = tabs[-1]['ra'], tabs[-1]['dec'], tabs[-1]['error']
+		names = [t['name'] for t in tabs]
+		res = run(tabs, radius, comp)
+		out[tag + '_area'] = np.array([span**2]); out[tag + '_radius'] = np.array([radius]); out[tag + '_completeness'] = np.atleast_1d(comp)
+		out.update(table_arrays(res, names, tag + '_'))
+		out.update(cli_correction_prefixed(ref, tabs, radius, comp, tag + '_'))
+		print('%s: %d rows, ncat %s, %d rows corrected (sum %.6f)' % (tag, len(res), np.bincount(res['ncat'].values), len(out[tag + '_cli_changed_rows']), out[tag + '_cli_sum_correction'][0]))
+	save('kway', **out)
+
+
+if __name__ == '__main__' and ('kway' in sys.argv[1:] or not sys.argv[1:]):
+	gen_kway()

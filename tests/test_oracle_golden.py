@@ -157,6 +157,25 @@ def test_edge_cases():
 	assert_table_matches(t, g, 'k4_', ['T0', 'T1', 'T2', 'T3'], **TIGHT)
 
 
+def test_four_and_five_way_with_script_correction():
+	"""generic k: presence patterns, vector completeness, and nway.py:366-420 for k > 3"""
+	g = golden('kway')
+	for tag, k in (('k4c', 4), ('k5', 5)):
+		names = ['T%d' % i for i in range(k)]
+		tabs = [cat(names[i], g['%s_ra%d' % (tag, i)], g['%s_dec%d' % (tag, i)], g['%s_err%d' % (tag, i)], g[tag + '_area'][0]) for i in range(k)]
+		comp = g[tag + '_completeness']
+		comp = float(comp[0]) if len(comp) == 1 else comp
+		t = orc.nway_match(tabs, float(g[tag + '_radius'][0]), comp, literal_groups=True)
+		assert_table_matches(t, g, tag + '_', names, **TIGHT)
+		tc = orc.nway_match(tabs, float(g[tag + '_radius'][0]), comp, correction='cli')
+		delta = tc['dist_bayesfactor'] - tc['dist_bayesfactor_uncorrected']
+		np.testing.assert_array_equal(np.flatnonzero(delta != 0), g[tag + '_cli_changed_rows'])
+		np.testing.assert_allclose(delta[delta != 0], g[tag + '_cli_correction'], rtol=1e-12)
+		tcc = orc_c.nway_match(tabs, float(g[tag + '_radius'][0]), comp, correction='cli')
+		np.testing.assert_allclose(tcc['dist_bayesfactor'], tc['dist_bayesfactor'], rtol=1e-12)
+		np.testing.assert_array_equal(tcc['match_flag'], tc['match_flag'])
+
+
 def test_sphere_scheme_equals_bruteforce():
 	"""all-sky inputs (reference: HEALPix branch, not executable here): the oracle's sweep is
 	checked against an O(N^2) evaluation of its own definition incl. poles and the RA seam"""
