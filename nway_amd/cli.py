@@ -297,9 +297,13 @@ def main(argv=None):
 			col, ti, func, mag_all = cli_magnitude_bias(mag, magfile, table_names, tables, idx_columns, sep_max, post,
 				mag_include_radius, mag_exclude_radius, args.mag_auto_minprob, args.radius)
 			d_bias = t.empty(res.nrows, dtype=t.float64, device=device)
-			_hip.check(lib.nwayhip_bias_lookup(res.nrows, _hip.ptr(res.column('idx', ti)), _hip.ptr(_hip.to_device(mag_all, device)),
-				len(func.edges), _hip.ptr(_hip.to_device(func.edges, device)), _hip.ptr(_hip.to_device(func.values, device)),
-				_hip.ptr(total), _hip.ptr(d_bias), _hip.current_stream_ptr(device)))
+			# named: a temporary tensor would be released (and its block handed to the next
+			# allocation) as soon as its address had been taken
+			d_mag = _hip.to_device(mag_all, device)
+			d_edges = _hip.to_device(func.edges, device)
+			d_ratio = _hip.to_device(func.values, device)
+			_hip.check(lib.nwayhip_bias_lookup(res.nrows, _hip.ptr(res.column('idx', ti)), _hip.ptr(d_mag), len(func.edges),
+				_hip.ptr(d_edges), _hip.ptr(d_ratio), _hip.ptr(total), _hip.ptr(d_bias), _hip.current_stream_ptr(device)))
 			biases.append(col)
 			columns.append(('bias_%s' % col, 'E', d_bias.cpu().numpy()))
 		print()

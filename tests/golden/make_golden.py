@@ -691,3 +691,114 @@ def gen_kway():
 
 if __name__ == '__main__' and ('kway' in sys.argv[1:] or not sys.argv[1:]):
 	gen_kway()
+
+
+def script_mag_numerics(tables, radius, completeness, mag_include_radius=None, mag_exclude_radius=None, minprob=0.9,
+		prob_ratio_secondary=0.5):
+	"""What the SCRIPT computes with ``--mag T:col auto`` for every magnitude column of ``tables``:
+	script_numerics' float32 trip, then nway.py:430-527 transcribed (its selection indexes the
+	weights by the SELECTED rows, nway.py:471, where the API uses the defined ones; the
+	separation column it thresholds is the float32 one), then the reference's group statistics."""
+	bd = ref.bayesdist
+	if mag_exclude_radius is None:
+		mag_exclude_radius = mag_include_radius
+	table, resultstable, separations, errors = ref._create_match_table(tables, radius, logger=LOG)
+	sep32 = [[cell.astype(np.float32) if i < j else cell for j, cell in enumerate(row)] for i, row in enumerate(separations)]
+	dens, dens_plus = ref._compute_source_densities(tables, logger=LOG)
+	prior, log_bf = ref._compute_single_log_bf(tables, dens, dens_plus, table, sep32, errors, completeness, logger=LOG)
+	assert len(tables) == 3  # the correction only touches row 0 of a group; k = 3 closed form not needed: reuse the loop
+	ncat = table['ncat'].values
+	prim = resultstable[:, 0]
+	starts = np.flatnonzero(np.r_[True, prim[1:] != prim[:-1]])
+	ends = np.r_[starts[1:], len(prim)]
+	group_of = np.repeat(np.arange(len(starts)), ends - starts)
+	log_bf = log_bf.copy()
+	uncorrected = log_bf.copy()
+	for i in np.where(ncat <= len(tables) - 2)[0]:
+		missing_cats = [k for k, sep in enumerate(sep32[0]) if np.isnan(sep[i])]
+		best_logpost = 0
+		g = group_of[i]
+		for j in range(starts[g], ends[g]):
+			if not (ncat[j] > 2):
+				continue
+			augmented_cats = [k for k in missing_cats if not np.isnan(sep32[0][k][j])]
+			if len(augmented_cats) >= 2:
+				prior_j = dens[augmented_cats[0]] / np.prod(dens_plus[augmented_cats])
+				errors_selected = [[errors[k][j]] for k in augmented_cats]
+				separations_selected = [[[sep32[k][k2][j]] for k2 in augmented_cats] for k in augmented_cats]
+				log_bf_j = bd.log_bf(np.array(separations_selected), np.array(errors_selected))
+				logpost_j = bd.unnormalised_log_posterior(prior_j, log_bf_j, len(augmented_cats))[0]
+				if logpost_j > best_logpost:
+					best_logpost = logpost_j
+		if best_logpost > 0:
+			log_bf[i] += best_logpost
+	post = bd.posterior(prior, log_bf)
+	sep_max32 = table['Separation_max'].values.astype(np.float32)
+	biases, hist_texts = {}, {}
+	for ti, t in enumerate(tables):
+		res = resultstable[:, ti]
+		res_defined = res != -1
+		for magvals, magname in zip(t['mags'], t['magnames']):
+			col = '%s_%s' % (t['name'], magname)
+			table_col = np.where(res_defined, magvals[res], -99.)  # match_multiple: gathered, -99 where missing
+			mag_all = magvals
+			mag_all[mag_all == -99] = np.nan
+			mask_all = ~np.logical_or(np.isnan(mag_all), np.isinf(mag_all))
+			if mag_include_radius is not None:
+				selection = sep_max32 < mag_include_radius
+				selection_possible = sep_max32 < mag_exclude_radius
+				selection_weights = np.ones(len(selection))
+			else:
+				selection = post > minprob
+				selection_weights = post
+				selection_possible = post > 0.01
+			selection = np.logical_and(selection, res_defined)
+			selection_weights = selection_weights[selection]
+			selection_possible = np.logical_and(selection_possible, res_defined)
+			rows, unique_indices = np.unique(res[selection], return_index=True)
+			rows_weights = selection_weights[unique_indices]
+			assert len(rows) > 1
+			mag_sel = mag_all[rows]
+			rows_possible = np.unique(res[selection_possible])
+			mask_others = mask_all.copy()
+			mask_others[rows_possible] = False
+			mask_sel = ~np.logical_or(np.isnan(mag_sel), np.isinf(mag_sel))
+			bins, hist_sel, hist_all = ref.magnitudeweights.adaptive_histograms(mag_all[mask_others], mag_sel[mask_sel], weights=rows_weights[mask_sel])
+			import io
+			f = io.BytesIO()
+			f.write(b'# lo hi selected others\n')
+			np.savetxt(f, np.transpose([bins[:-1], bins[1:], hist_sel, hist_all]), fmt=['%10.5f'] * 4)
+			hist_texts[col] = f.getvalue()
+			func = ref.magnitudeweights.fitfunc_histogram(bins, hist_sel, hist_all)
+			with np.errstate(divide='ignore'):
+				weights = np.log10(func(table_col))
+			weights[np.isnan(weights)] = 0
+			biases[col] = weights
+	total = log_bf + sum(biases.values())
+	table = table.assign(dist_bayesfactor_uncorrected=uncorrected, dist_bayesfactor=log_bf, dist_post=post)
+	final = ref._compute_final_probabilities(tables, table, prob_ratio_secondary, prior, total, logger=LOG)
+	return final, dict((c, 10**w) for c, w in biases.items()), hist_texts
+
+
+def gen_magscript():
+	"""the command line's magnitude priors (--mag T:col auto, by posterior and by radius) on the
+	mag3 catalogues; expected FITS column values are these cast to float32"""
+	from goldenutil import mag3_tables
+	out = {}
+	names = ['XMM', 'OPT', 'IRAC']
+	for tag, kw in (('post', dict()), ('rad', dict(mag_include_radius=3.3))):
+		final, biases, texts = script_mag_numerics(mag3_tables(), 20., 0.9, **kw)
+		out.update(checksums(final, names, tag + '_'))
+		out.update(subset_rows(final, names, 17, tag + '_'))
+		mask = (final['XMM'].values % 17) == 0
+		for col, v in biases.items():
+			out['%s_sum_bias_%s' % (tag, col)] = np.array([v.sum()])
+			out['%s_sub_bias_%s' % (tag, col)] = v[mask]
+			out['%s_hist_%s' % (tag, col)] = np.frombuffer(texts[col], dtype=np.uint8)
+		print('magscript %s: %d rows, flags %s' % (tag, len(final), np.bincount(final['match_flag'].values)))
+	save('magscript', **out)
+
+
+if __name__ == '__main__' and ('magscript' in sys.argv[1:] or not sys.argv[1:]):
+	sys.path.insert(0, os.path.dirname(HERE))
+	gen_magscript()

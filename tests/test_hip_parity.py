@@ -395,6 +395,47 @@ def test_cli_fits_in_fits_out(nw, tmp_path, monkeypatch):
 	np.testing.assert_array_equal(out3.data['match_flag'], api3['match_flag'])
 
 
+def test_cli_magnitude_priors_golden(nw, tmp_path, monkeypatch):
+	"""nway.py --mag T:col auto (three columns over two catalogues, 3-way, by posterior and by
+	radius) against the script's logic run on the reference's functions (make_golden.py:
+	script_mag_numerics): float32 numerics, correction loop, the script's own selection rule"""
+	from nway_amd import _fits, cli
+	from goldenutil import mag3_tables
+	g = golden('magscript')
+	monkeypatch.chdir(tmp_path)
+	X, O, I = mag3_tables()
+	for t, extra in ((X, [('pos_err', 'D', X['error'])]), (O, [('R', 'D', O['mags'][0]), ('I', 'D', O['mags'][1])]), (I, [('CH1', 'D', I['mags'][0])])):
+		n = len(t['ra'])
+		_fits.write_table('%s.fits' % t['name'], [('ID', 'J', np.arange(n)), ('RA', 'D', t['ra']), ('DEC', 'D', t['dec'])] + extra,
+			t['name'], table_header={'SKYAREA': t['area']})
+	names = ['XMM', 'OPT', 'IRAC']
+	base = ['--radius', '20', 'XMM.fits', ':pos_err', 'OPT.fits', '0.1', 'IRAC.fits', '0.5', '--prior-completeness', '0.9',
+		'--mag', 'OPT:R', 'auto', '--mag', 'OPT:I', 'auto', '--mag', 'IRAC:CH1', 'auto']
+	for tag, extra in (('post', []), ('rad', ['--mag-radius', '3.3'])):
+		assert cli.main(base + extra + ['--out', tag + '.fits']) == 0
+		out = _fits.read_table(tag + '.fits')
+		d = out.data
+		t = {'XMM': np.asarray(d['XMM_ID'], dtype=np.int64)}
+		for n in names[1:]:
+			ids = np.asarray(d[n + '_ID'], dtype=np.int64)
+			t[n] = np.where(ids == -99, -1, ids)
+		for i in range(3):
+			for j in range(i + 1, 3):
+				t['Separation_%s_%s' % (names[i], names[j])] = np.asarray(d['Separation_%s_%s' % (names[j], names[i])], dtype=float)
+		for src, dst in (('Separation_max', 'Separation_max'), ('dist_bayesfactor', 'dist_bayesfactor_uncorrected'),
+				('dist_bayesfactor_corrected', 'dist_bayesfactor'), ('dist_post', 'dist_post'), ('p_single', 'p_single'),
+				('p_any', 'prob_has_match'), ('p_i', 'prob_this_match')):
+			t[dst] = np.asarray(d[src], dtype=float)
+		t['ncat'] = np.asarray(d['ncat'], dtype=np.int64)
+		t['match_flag'] = np.asarray(d['match_flag'], dtype=np.int64)
+		assert_checksums_match(t, g, tag + '_', names, rtol=1e-6)
+		rows = g[tag + '_sub_rows']
+		assert_table_matches(t, g, tag + '_sub_', names, rows=rows, rtol=2e-6, atol=1e-9)
+		for col in ('OPT_R', 'OPT_I', 'IRAC_CH1'):
+			np.testing.assert_allclose(np.asarray(d['bias_' + col], dtype=float)[rows], g['%s_sub_bias_%s' % (tag, col)], rtol=2e-6, err_msg=col)
+			assert open(col + '_fit.txt', 'rb').read() == g['%s_hist_%s' % (tag, col)].tobytes(), col
+
+
 def test_nwaylib_alias(nw):
 	import nwaylib
 	import nwaylib.bayesdistance as bd
