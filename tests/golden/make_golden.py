@@ -802,3 +802,95 @@ def gen_magscript():
 if __name__ == '__main__' and ('magscript' in sys.argv[1:] or not sys.argv[1:]):
 	sys.path.insert(0, os.path.dirname(HERE))
 	gen_magscript()
+
+
+def fuzz_case(seed):
+	"""one small randomized configuration (inputs + the options of nway_match)"""
+	rng = np.random.RandomState(1000 + seed)
+	k = int(rng.choice([2, 2, 3, 3, 4]))
+	where = ['flat', 'flat', 'flat', 'north', 'seam', 'south', 'high'][seed % 7]
+	radius = float(rng.choice([3., 8., 15., 30.]))
+	span = radius / 3600. * rng.uniform(6, 14)   # box of a few search radii: dense groups
+	n0 = int(rng.randint(3, 40))
+	sizes = [n0] + [int(rng.randint(10, 120 if k < 4 else 60)) for _ in range(k - 1)]
+	if where == 'flat':
+		c_ra, c_dec = rng.uniform(20, 340), rng.uniform(-40, 40)
+		if seed % 3 == 0:
+			c_dec = rng.uniform(-0.3, 0.3) * span  # straddle the equator
+	elif where == 'high':
+		c_ra, c_dec = rng.uniform(20, 340), rng.choice([-1, 1]) * rng.uniform(50, 80)
+	elif where == 'seam':
+		c_ra, c_dec = 0.0, rng.uniform(-30, 30)
+	else:
+		c_ra, c_dec = rng.uniform(0, 360), (90.0 if where == 'north' else -90.0)
+	tabs = []
+	for i, n in enumerate(sizes):
+		if where in ('north', 'south'):
+			d = np.abs(rng.normal(0, span, size=n))
+			dec = 90 - d if where == 'north' else -90 + d
+			ra = rng.uniform(0, 360, size=n)
+		else:
+			dec = c_dec + rng.uniform(-span, span, size=n) / 2
+			ra = np.mod(c_ra + rng.uniform(-span, span, size=n) / 2 / np.cos(np.radians(c_dec)), 360.)
+		if i > 0:  # counterparts of some primaries
+			m = min(n, n0)
+			has = rng.uniform(size=m) < 0.6
+			pr, pd = _scatter(rng, tabs[0]['ra'][:m][has], tabs[0]['dec'][:m][has], radius / 4)
+			ra[:m][has], dec[:m][has] = pr, pd
+		err = rng.uniform(0.2, radius / 3, size=n) if rng.uniform() < 0.7 else rng.uniform(0.2, radius / 3) * np.ones(n)
+		tabs.append(cat('C%d' % i, ra, dec, err, (span * 1.0)**2 if where not in ('north', 'south') else np.pi * (2 * span)**2))
+	comp = float(rng.uniform(0.5, 1.0)) if rng.uniform() < 0.5 else np.r_[1.0, rng.uniform(0.4, 1.0, size=k - 1)]
+	opts = dict(prob_ratio_secondary=float(rng.choice([0.5, 0.2, 0.8])), min_prob=float(rng.choice([0., 0., 0.03])),
+		consider_unrelated_associations=bool(rng.uniform() < 0.8))
+	if seed % 4 == 1:  # a supplied magnitude histogram on the last catalogue
+		mag = rng.normal(22, 2, size=sizes[-1])
+		mag[rng.uniform(size=sizes[-1]) < 0.1] = -99
+		mag[rng.uniform(size=sizes[-1]) < 0.05] = np.nan
+		edges = np.sort(rng.uniform(16, 28, size=7))
+		hs, ha = rng.uniform(0, 1, size=6), rng.uniform(0, 1, size=6)
+		hs[rng.randint(6)] = 0.0
+		ha[rng.randint(6)] = 0.0
+		tabs[-1]['mags'], tabs[-1]['magnames'], tabs[-1]['maghists'] = [mag], ['M'], [(edges[:-1], edges[1:], hs, ha)]
+	return tabs, radius, comp, opts
+
+
+def gen_fuzz(nseeds=35):
+	"""small randomized configurations through the reference: k = 2..4, flat cells and the HEALPix
+	branch (poles, seam, high declination; oracle/healpix.py standing in for healpy), scalar and
+	vector completeness, secondary ratio, min_prob, supplied magnitude histograms"""
+	out = dict(nseeds=np.array([nseeds]))
+	cwd = os.getcwd()
+	import tempfile
+	os.chdir(tempfile.mkdtemp(prefix='nwayfuzz_'))
+	try:
+		for seed in range(nseeds):
+			tabs, radius, comp, opts = fuzz_case(seed)
+			tag = 'f%d_' % seed
+			for i, t in enumerate(tabs):
+				out[tag + 'ra%d' % i], out[tag + 'dec%d' % i], out[tag + 'err%d' % i] = t['ra'].copy(), t['dec'].copy(), t['error'].copy()
+				out[tag + 'area%d' % i] = np.array([t['area']])
+			out[tag + 'k'] = np.array([len(tabs)])
+			out[tag + 'radius'] = np.array([radius])
+			out[tag + 'completeness'] = np.atleast_1d(comp)
+			out[tag + 'opts'] = np.array([opts['prob_ratio_secondary'], opts['min_prob'], float(opts['consider_unrelated_associations'])])
+			if tabs[-1]['mags']:
+				out[tag + 'mag'] = tabs[-1]['mags'][0].copy()
+				out[tag + 'maghist'] = np.array([np.r_[h, np.nan] if len(h) == 6 else h for h in (np.r_[tabs[-1]['maghists'][0][0], tabs[-1]['maghists'][0][1][-1]],) + tuple(tabs[-1]['maghists'][0][2:])])
+			names = [t['name'] for t in tabs]
+			try:
+				res = ref.nway_match(tabs, match_radius=radius, prior_completeness=comp, store_mag_hists=False, logger=LOG, **opts)
+			except ref.EmptyResultException:
+				out[tag + 'empty'] = np.array([1])
+				print('fuzz %d: empty' % seed)
+				continue
+			out.update(table_arrays(res, names, tag))
+			if tabs[-1]['mags']:
+				out[tag + 'bias'] = res['bias_%s_M' % names[-1]].values
+			print('fuzz %2d: k=%d %s rows=%d flags=%s' % (seed, len(tabs), ['flat', 'flat', 'flat', 'north', 'seam', 'south', 'high'][seed % 7], len(res), np.bincount(res['match_flag'].values, minlength=3)))
+	finally:
+		os.chdir(cwd)
+	save('fuzz', **out)
+
+
+if __name__ == '__main__' and ('fuzz' in sys.argv[1:] or not sys.argv[1:]):
+	gen_fuzz()

@@ -106,6 +106,25 @@ def mag3_tables():
 	return [X, O, I]
 
 
+def fuzz_cases():
+	"""the randomized configurations of tests/golden/fuzz.npz (make_golden.py:gen_fuzz):
+	yields (tag, tables, radius, completeness, options, golden)"""
+	g = golden('fuzz')
+	for seed in range(int(g['nseeds'][0])):
+		tag = 'f%d_' % seed
+		k = int(g[tag + 'k'][0])
+		tabs = [cat('C%d' % i, g[tag + 'ra%d' % i], g[tag + 'dec%d' % i], g[tag + 'err%d' % i], float(g[tag + 'area%d' % i][0])) for i in range(k)]
+		comp = g[tag + 'completeness']
+		comp = float(comp[0]) if len(comp) == 1 else comp
+		ratio, min_prob, unrelated = g[tag + 'opts']
+		opts = dict(prob_ratio_secondary=float(ratio), min_prob=float(min_prob), consider_unrelated_associations=bool(unrelated))
+		if tag + 'mag' in g.files:
+			h = g[tag + 'maghist']
+			tabs[-1]['mags'], tabs[-1]['magnames'] = [g[tag + 'mag'].copy()], ['M']
+			tabs[-1]['maghists'] = [(h[0][:-1], h[0][1:], h[1][:-1], h[2][:-1])]
+		yield tag, tabs, float(g[tag + 'radius'][0]), comp, opts, g
+
+
 def idx_hash(idx):
 	idx = np.asarray(idx).astype(np.int64)
 	w = np.arange(1, len(idx) + 1, dtype=np.uint64)

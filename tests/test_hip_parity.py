@@ -182,6 +182,24 @@ def test_four_and_five_way_golden(nw):
 			np.testing.assert_allclose(tc[c], to[c], rtol=RTOL, atol=ATOL, err_msg=c)
 
 
+def test_randomized_configurations_golden(nw, tmp_path, monkeypatch):
+	"""35 small random configurations run through the reference: flat cells and its HEALPix branch
+	(poles, seam, high declination), k = 2..4, scalar / vector completeness, secondary ratio,
+	min_prob, supplied magnitude histograms (with empty bins on either side)"""
+	from goldenutil import fuzz_cases
+	monkeypatch.chdir(tmp_path)
+	for tag, tabs, radius, comp, opts, g in fuzz_cases():
+		names = [t['name'] for t in tabs]
+		if tag + 'empty' in g.files:
+			with pytest.raises(nw.EmptyResultException):
+				run(nw, tabs, radius, comp, store_mag_hists=False, **opts)
+			continue
+		t = run(nw, tabs, radius, comp, store_mag_hists=False, **opts)
+		assert_table_matches(t, g, tag, names)
+		if tabs[-1]['mags']:
+			np.testing.assert_allclose(t['bias_%s_M' % names[-1]], g[tag + 'bias'], rtol=RTOL, err_msg=tag)
+
+
 def test_script_numerics_golden(nw):
 	"""f32_roundtrip: the numbers of the script nway.py (separations through a float32 FITS column
 	before log_bf and the correction loop), produced with the reference's own

@@ -176,6 +176,22 @@ def test_four_and_five_way_with_script_correction():
 		np.testing.assert_array_equal(tcc['match_flag'], tc['match_flag'])
 
 
+def test_randomized_configurations():
+	"""35 small random configurations run through the reference (flat cells and its HEALPix
+	branch at the poles, the seam and high declination; k = 2..4; completeness, ratio, min_prob)"""
+	from goldenutil import fuzz_cases
+	n = 0
+	for tag, tabs, radius, comp, opts, g in fuzz_cases():
+		if tabs[-1]['mags']:
+			continue  # magnitude priors are host logic of the product, not part of the oracle
+		names = [t['name'] for t in tabs]
+		t = orc.nway_match(tabs, radius, comp, prob_ratio_secondary=opts['prob_ratio_secondary'], min_prob=opts['min_prob'],
+			correction='api', literal_groups=True)
+		assert_table_matches(t, g, tag, names, **TIGHT)
+		n += 1
+	assert n >= 20
+
+
 def test_sphere_scheme_equals_bruteforce():
 	"""all-sky inputs (reference: HEALPix branch, not executable here): the oracle's sweep is
 	checked against an O(N^2) evaluation of its own definition incl. poles and the RA seam"""
