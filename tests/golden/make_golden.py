@@ -886,6 +886,11 @@ def gen_fuzz(nseeds=35):
 			out.update(table_arrays(res, names, tag))
 			if tabs[-1]['mags']:
 				out[tag + 'bias'] = res['bias_%s_M' % names[-1]].values
+			else:
+				# the same configuration with the script's numerics and its correction loop
+				plain = [cat(t['name'], t['ra'], t['dec'], t['error'], t['area']) for t in tabs]
+				sres = script_numerics(plain, radius, comp, prob_ratio_secondary=opts['prob_ratio_secondary'])
+				out.update(table_arrays(sres, names, tag + 'script_'))
 			print('fuzz %2d: k=%d %s rows=%d flags=%s' % (seed, len(tabs), ['flat', 'flat', 'flat', 'north', 'seam', 'south', 'high'][seed % 7], len(res), np.bincount(res['match_flag'].values, minlength=3)))
 	finally:
 		os.chdir(cwd)

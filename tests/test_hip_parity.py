@@ -198,6 +198,10 @@ def test_randomized_configurations_golden(nw, tmp_path, monkeypatch):
 		assert_table_matches(t, g, tag, names)
 		if tabs[-1]['mags']:
 			np.testing.assert_allclose(t['bias_%s_M' % names[-1]], g[tag + 'bias'], rtol=RTOL, err_msg=tag)
+		else:
+			# the script's numerics and correction loop on the same configuration
+			ts = run(nw, tabs, radius, comp, prob_ratio_secondary=opts['prob_ratio_secondary'], unrelated_associations='cli', f32_roundtrip=True)
+			assert_table_matches(ts, g, tag + 'script_', names)
 
 
 def test_script_numerics_golden(nw):

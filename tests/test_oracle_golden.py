@@ -188,6 +188,10 @@ def test_randomized_configurations():
 		t = orc.nway_match(tabs, radius, comp, prob_ratio_secondary=opts['prob_ratio_secondary'], min_prob=opts['min_prob'],
 			correction='api', literal_groups=True)
 		assert_table_matches(t, g, tag, names, **TIGHT)
+		# ... and with the script's numerics and correction loop (float32 separations), both oracles
+		for oracle in (orc, orc_c):
+			ts = oracle.nway_match(tabs, radius, comp, prob_ratio_secondary=opts['prob_ratio_secondary'], correction='cli', f32_roundtrip=True)
+			assert_table_matches(ts, g, tag + 'script_', names, **TIGHT)
 		n += 1
 	assert n >= 20
 
