@@ -899,3 +899,58 @@ def gen_fuzz(nseeds=35):
 
 if __name__ == '__main__' and ('fuzz' in sys.argv[1:] or not sys.argv[1:]):
 	gen_fuzz()
+
+
+def magmix_tables(seed=2024):
+	"""3-way, 400 primaries; magnitude columns on the PRIMARY (supplied histogram) and on both
+	secondaries (learned).  tests/goldenutil.py:magmix_tables stores nothing: the arrays are saved."""
+	rng = np.random.RandomState(seed)
+	n0, n1, n2 = 400, 3000, 2500
+	span = 0.2
+	p_ra, p_dec = rng.uniform(40, 40 + span, n0), rng.uniform(-5, -5 + span, n0)
+	tabs = [cat('P', p_ra, p_dec, rng.uniform(0.5, 2.0, n0), span**2)]
+	tabs[0]['mags'] = [rng.normal(18, 1, n0)]
+	tabs[0]['magnames'] = ['F']
+	edges = np.linspace(14, 22, 9)
+	tabs[0]['maghists'] = [(edges[:-1], edges[1:], rng.uniform(0.05, 1, 8), rng.uniform(0.05, 1, 8))]
+	for name, n, frac, sig, m0 in (('A', n1, 0.75, 0.4, 23.0), ('B', n2, 0.6, 0.8, 21.0)):
+		ra, dec = rng.uniform(40, 40 + span, n), rng.uniform(-5, -5 + span, n)
+		mag = rng.normal(m0, 1.2, n)
+		has = np.flatnonzero(rng.uniform(size=n0) < frac)
+		pr, pd = _scatter(rng, p_ra[has], p_dec[has], sig)
+		ra[:len(has)], dec[:len(has)] = pr, pd
+		mag[:len(has)] = rng.normal(m0 - 2.5, 0.8, len(has))
+		mag[rng.choice(n, n // 40, replace=False)] = -99
+		mag[rng.choice(n, n // 100, replace=False)] = np.nan
+		order = rng.permutation(n)
+		t = cat(name, ra[order], dec[order], (0.3 if name == 'A' else 0.6) * np.ones(n), span**2)
+		t['mags'], t['magnames'], t['maghists'] = [mag[order]], ['M'], [None]
+		tabs.append(t)
+	return tabs
+
+
+def gen_magmix():
+	out = {}
+	tabs = magmix_tables()
+	for i, t in enumerate(tabs):
+		out['ra%d' % i], out['dec%d' % i], out['err%d' % i], out['mag%d' % i] = t['ra'], t['dec'], t['error'], t['mags'][0].copy()
+	out['area'] = np.array([tabs[0]['area']])
+	out['hist0'] = np.array([np.r_[tabs[0]['maghists'][0][0], tabs[0]['maghists'][0][1][-1]], np.r_[tabs[0]['maghists'][0][2], np.nan], np.r_[tabs[0]['maghists'][0][3], np.nan]])
+	names = ['P', 'A', 'B']
+	cwd = os.getcwd()
+	import tempfile
+	os.chdir(tempfile.mkdtemp(prefix='nwaymagmix_'))
+	try:
+		for tag, kw in (('rad_', dict(mag_include_radius=1.5, mag_exclude_radius=6.0)), ('post_', dict(magauto_post_single_minvalue=0.7))):
+			res = ref.nway_match(magmix_tables(), match_radius=12., prior_completeness=np.array([1.0, 0.8, 0.7]), store_mag_hists=False, logger=LOG, **kw)
+			out.update(table_arrays(res, names, tag))
+			for b in ('bias_P_F', 'bias_A_M', 'bias_B_M'):
+				out[tag + b] = res[b].values
+			print('magmix %s %d rows flags %s' % (tag, len(res), np.bincount(res['match_flag'].values)))
+	finally:
+		os.chdir(cwd)
+	save('magmix', **out)
+
+
+if __name__ == '__main__' and ('magmix' in sys.argv[1:] or not sys.argv[1:]):
+	gen_magmix()

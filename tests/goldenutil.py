@@ -106,6 +106,20 @@ def mag3_tables():
 	return [X, O, I]
 
 
+def magmix_tables():
+	"""3-way with magnitude columns on the primary (supplied histogram) and both secondaries
+	(learned); arrays stored in tests/golden/magmix.npz"""
+	g = golden('magmix')
+	tabs = []
+	for i, name in enumerate('PAB'):
+		t = cat(name, g['ra%d' % i], g['dec%d' % i], g['err%d' % i], float(g['area'][0]))
+		t['mags'], t['magnames'], t['maghists'] = [g['mag%d' % i].copy()], ['F' if i == 0 else 'M'], [None]
+		tabs.append(t)
+	h = g['hist0']
+	tabs[0]['maghists'] = [(h[0][:-1], h[0][1:], h[1][:-1], h[2][:-1])]
+	return tabs
+
+
 def fuzz_cases():
 	"""the randomized configurations of tests/golden/fuzz.npz (make_golden.py:gen_fuzz):
 	yields (tag, tables, radius, completeness, options, golden)"""

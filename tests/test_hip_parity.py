@@ -277,6 +277,21 @@ def test_three_way_magnitude_priors_golden(nw, tmp_path, monkeypatch):
 		np.testing.assert_allclose(np.sum(t[b]), g['m3_sum_' + b][0], rtol=1e-9, err_msg=b)
 
 
+def test_magnitude_priors_on_every_catalogue_golden(nw, tmp_path, monkeypatch):
+	"""magnitude columns on the PRIMARY (supplied histogram) and on both secondaries (learned),
+	with an exclusion radius different from the inclusion radius, and with a lowered posterior
+	threshold (__init__.py:324-336)"""
+	from goldenutil import magmix_tables
+	g = golden('magmix')
+	monkeypatch.chdir(tmp_path)
+	comp = np.array([1.0, 0.8, 0.7])
+	for tag, kw in (('rad_', dict(mag_include_radius=1.5, mag_exclude_radius=6.0)), ('post_', dict(magauto_post_single_minvalue=0.7))):
+		t = run(nw, magmix_tables(), 12., comp, store_mag_hists=False, **kw)
+		assert_table_matches(t, g, tag, ['P', 'A', 'B'])
+		for b in ('bias_P_F', 'bias_A_M', 'bias_B_M'):
+			np.testing.assert_allclose(t[b], g[tag + b], rtol=RTOL, err_msg=tag + b)
+
+
 def test_empty_secondary_catalogue(nw):
 	tp = cat('P', [10.0], [10.0], [1.0], 1.0)
 	ts = cat('S', np.zeros(0), np.zeros(0), np.zeros(0), 1.0)
