@@ -954,3 +954,43 @@ def gen_magmix():
 
 if __name__ == '__main__' and ('magmix' in sys.argv[1:] or not sys.argv[1:]):
 	gen_magmix()
+
+
+def gen_sparse():
+	"""sparse fields (chance neighbours per primary << 1): the inputs on which the product takes its
+	fused sparse kernels -- 2-, 3- and 4-way, API and script numerics, flat cells and (same
+	tables moved to Dec 60..70) the HEALPix branch"""
+	rng = np.random.RandomState(314)
+	n0, ns = 1500, 12000
+	out = dict(radius=np.array([6.]), completeness=np.array([1.0, 0.9, 0.8, 0.7]))
+	p_ra, p_dec = rng.uniform(100, 110, n0), rng.uniform(-5, 5, n0)
+	tabs = [cat('P', p_ra, p_dec, rng.uniform(0.3, 1.5, n0), 100.)]
+	for name, frac, sig in (('A', 0.8, 0.5), ('B', 0.6, 0.8), ('C', 0.5, 1.0)):
+		ra, dec = rng.uniform(100, 110, ns), rng.uniform(-5, 5, ns)
+		has = np.flatnonzero(rng.uniform(size=n0) < frac)
+		pr, pd = _scatter(rng, p_ra[has], p_dec[has], sig)
+		ra[:len(has)], dec[:len(has)] = pr, pd
+		# a few primaries with two or three counterparts in the same catalogue
+		extra = has[:25]
+		er, ed = _scatter(rng, p_ra[extra], p_dec[extra], 1.5)
+		ra[len(has):len(has) + 25], dec[len(has):len(has) + 25] = er, ed
+		order = rng.permutation(ns)
+		tabs.append(cat(name, ra[order], dec[order], rng.uniform(0.2, 0.6, ns), 100.))
+	for i, t in enumerate(tabs):
+		out['ra%d' % i], out['dec%d' % i], out['err%d' % i] = t['ra'], t['dec'], t['error']
+	names = [t['name'] for t in tabs]
+	for shift, where in ((0.0, 'flat'), (65.0, 'high')):
+		moved = [cat(t['name'], t['ra'], t['dec'] + shift, t['error'], t['area']) for t in tabs]
+		for k in (2, 3, 4):
+			tag = '%s%d_' % (where, k)
+			comp = out['completeness'][:k]
+			res = run(moved[:k], 6., comp)
+			out.update(table_arrays(res, names[:k], tag))
+			sres = script_numerics(moved[:k], 6., comp)
+			out.update(table_arrays(sres, names[:k], tag + 'script_'))
+			print('sparse %s k=%d: %d rows, ncat %s' % (where, k, len(res), np.bincount(res['ncat'].values)))
+	save('sparse', **out)
+
+
+if __name__ == '__main__' and ('sparse' in sys.argv[1:] or not sys.argv[1:]):
+	gen_sparse()

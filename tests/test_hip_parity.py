@@ -480,6 +480,30 @@ def test_nwaylib_alias(nw):
 	assert bd.log_bf2(0.3, 0.1, 0.2) == pytest.approx(11.840045223967955, rel=1e-14)
 
 
+def test_sparse_fields_golden(nw):
+	"""sparse 2-/3-/4-way tables run through the reference (flat cells, and moved to Dec 60..70 its
+	HEALPix branch), API and script numerics: the inputs on which the fused sparse kernels
+	(k_pairs_slots + k_tail2 / k_tailk) run -- and the same through the general kernels"""
+	from nway_amd import _hip
+	g = golden('sparse')
+	names = ['P', 'A', 'B', 'C']
+	for shift, where in ((0.0, 'flat'), (65.0, 'high')):
+		tabs = [cat(names[i], g['ra%d' % i], g['dec%d' % i] + shift, g['err%d' % i], 100.) for i in range(4)]
+		for k in (2, 3, 4):
+			tag = '%s%d_' % (where, k)
+			comp = g['completeness'][:k]
+			res = nw.run_match(tabs[:k], 6., comp, logger=nw.NullOutputLogger())
+			assert res.plan.params.link_slots == 0 and int(res.status[_hip.ST_FLAGS]) == 0  # the fused path, no fallback
+			res.plan.close()
+			assert_table_matches(run(nw, tabs[:k], 6., comp), g, tag, names[:k])
+			ts = run(nw, tabs[:k], 6., comp, unrelated_associations='cli', f32_roundtrip=True)
+			assert_table_matches(ts, g, tag + 'script_', names[:k])
+			general = nw.run_match(tabs[:k], 6., comp, link_slots=-1, logger=nw.NullOutputLogger())
+			np.testing.assert_array_equal(general.to_host('match_flag'), g[tag + 'match_flag'])
+			np.testing.assert_allclose(general.to_host('p_i'), g[tag + 'prob_this_match'], rtol=RTOL, atol=ATOL)
+			general.plan.close()
+
+
 def test_sparse_fast_path_and_its_fallback(nw):
 	"""2-way sparse inputs take the fused tail (links in fixed slots + single-pass scan); a primary
 	with more links than slots makes the run fall back to the general path; both paths and the

@@ -196,6 +196,26 @@ def test_randomized_configurations():
 	assert n >= 20
 
 
+def test_sparse_fields():
+	"""sparse 2-/3-/4-way tables, flat cells and HEALPix branch, API and script numerics"""
+	g = golden('sparse')
+	names = ['P', 'A', 'B', 'C']
+	for shift, where in ((0.0, 'flat'), (65.0, 'high')):
+		tabs = [cat(names[i], g['ra%d' % i], g['dec%d' % i] + shift, g['err%d' % i], 100.) for i in range(4)]
+		for k in (2, 3, 4):
+			tag = '%s%d_' % (where, k)
+			comp = g['completeness'][:k]
+			# sub-arcsecond separations at Dec 65: the difference in the Vincenty numerator
+			# (fastskymatch.py:40-41) cancels to ~1e-6 of its terms, so one ulp in a sine -- numpy's
+			# SIMD loops round differently from libm on array tails -- is 1e-10 of the result
+			tol = TIGHT if where == 'flat' else dict(rtol=1e-9, atol=1e-13)
+			t = orc.nway_match(tabs[:k], 6., comp, literal_groups=True)
+			assert_table_matches(t, g, tag, names[:k], **tol)
+			for oracle in (orc, orc_c):
+				ts = oracle.nway_match(tabs[:k], 6., comp, correction='cli', f32_roundtrip=True)
+				assert_table_matches(ts, g, tag + 'script_', names[:k], **(tol if oracle is orc else dict(rtol=1e-9, atol=1e-13)))
+
+
 def test_sphere_scheme_equals_bruteforce():
 	"""all-sky inputs (reference: HEALPix branch, not executable here): the oracle's sweep is
 	checked against an O(N^2) evaluation of its own definition incl. poles and the RA seam"""
