@@ -671,7 +671,8 @@ def gen_kway():
 	presence patterns of the Bayes factor / prior, and the script's unrelated-association correction
 	for k > 3 (rows with ncat <= k - 2 augmented by two or more of their missing catalogues)"""
 	out = {}
-	for tag, sizes, radius, comp, seed in (('k4c', (25, 160, 140, 120), 25., 0.7, 11), ('k5', (12, 25, 22, 20, 18), 20., np.array([1.0, 0.9, 0.8, 0.7, 0.6]), 19)):
+	for tag, sizes, radius, comp, seed in (('k4c', (25, 160, 140, 120), 25., 0.7, 11), ('k5', (12, 25, 22, 20, 18), 20., np.array([1.0, 0.9, 0.8, 0.7, 0.6]), 19),
+			('k6', (8, 12, 11, 10, 9, 9), 20., 0.8, 23), ('k8', (5, 7, 7, 6, 6, 6, 5, 5), 18., np.array([1.0, 0.95, 0.9, 0.85, 0.8, 0.75, 0.7, 0.65]), 29)):
 		rng = np.random.RandomState(seed)
 		span = 0.05 if tag == 'k4c' else 0.02
 		tabs = []
@@ -685,6 +686,7 @@ def gen_kway():
 		out[tag + '_area'] = np.array([span**2]); out[tag + '_radius'] = np.array([radius]); out[tag + '_completeness'] = np.atleast_1d(comp)
 		out.update(table_arrays(res, names, tag + '_'))
 		out.update(cli_correction_prefixed(ref, tabs, radius, comp, tag + '_'))
+		out.update(table_arrays(script_numerics(tabs, radius, comp), names, tag + '_script_'))
 		print('%s: %d rows, ncat %s, %d rows corrected (sum %.6f)' % (tag, len(res), np.bincount(res['ncat'].values), len(out[tag + '_cli_changed_rows']), out[tag + '_cli_sum_correction'][0]))
 	save('kway', **out)
 

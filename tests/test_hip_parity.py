@@ -163,7 +163,7 @@ def test_four_and_five_way_golden(nw):
 	"""generic k: presence patterns, vector completeness, and the script's unrelated-association
 	correction (nway.py:366-420) for k > 3, in both numerics"""
 	g = golden('kway')
-	for tag, k in (('k4c', 4), ('k5', 5)):
+	for tag, k in (('k4c', 4), ('k5', 5), ('k6', 6), ('k8', 8)):
 		names = ['T%d' % i for i in range(k)]
 		tabs = [cat(names[i], g['%s_ra%d' % (tag, i)], g['%s_dec%d' % (tag, i)], g['%s_err%d' % (tag, i)], g[tag + '_area'][0]) for i in range(k)]
 		comp = g[tag + '_completeness']
@@ -175,8 +175,10 @@ def test_four_and_five_way_golden(nw):
 		delta = tc['dist_bayesfactor'] - tc['dist_bayesfactor_uncorrected']
 		np.testing.assert_array_equal(np.flatnonzero(delta != 0), g[tag + '_cli_changed_rows'])
 		np.testing.assert_allclose(delta[delta != 0], g[tag + '_cli_correction'], rtol=1e-6)
+		ts = run(nw, tabs, radius, comp, unrelated_associations='cli', f32_roundtrip=True)
+		assert_table_matches(ts, g, tag + '_script_', names)
 		# everything downstream of the corrected Bayes factors, against the oracle
-		to = orc.nway_match(tabs, radius, comp, correction='cli')
+		to = orc_c.nway_match(tabs, radius, comp, correction='cli')
 		np.testing.assert_array_equal(tc['match_flag'], to['match_flag'])
 		for c in ('dist_post', 'p_single', 'prob_has_match', 'prob_this_match'):
 			np.testing.assert_allclose(tc[c], to[c], rtol=RTOL, atol=ATOL, err_msg=c)

@@ -160,7 +160,7 @@ def test_edge_cases():
 def test_four_and_five_way_with_script_correction():
 	"""generic k: presence patterns, vector completeness, and nway.py:366-420 for k > 3"""
 	g = golden('kway')
-	for tag, k in (('k4c', 4), ('k5', 5)):
+	for tag, k in (('k4c', 4), ('k5', 5), ('k6', 6), ('k8', 8)):
 		names = ['T%d' % i for i in range(k)]
 		tabs = [cat(names[i], g['%s_ra%d' % (tag, i)], g['%s_dec%d' % (tag, i)], g['%s_err%d' % (tag, i)], g[tag + '_area'][0]) for i in range(k)]
 		comp = g[tag + '_completeness']
@@ -174,6 +174,9 @@ def test_four_and_five_way_with_script_correction():
 		tcc = orc_c.nway_match(tabs, float(g[tag + '_radius'][0]), comp, correction='cli')
 		np.testing.assert_allclose(tcc['dist_bayesfactor'], tc['dist_bayesfactor'], rtol=1e-12)
 		np.testing.assert_array_equal(tcc['match_flag'], tc['match_flag'])
+		for oracle in (orc, orc_c):
+			ts = oracle.nway_match(tabs, float(g[tag + '_radius'][0]), comp, correction='cli', f32_roundtrip=True)
+			assert_table_matches(ts, g, tag + '_script_', names, **TIGHT)
 
 
 def test_randomized_configurations():
