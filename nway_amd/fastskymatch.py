@@ -55,6 +55,14 @@ def get_tablekeys(table, name, tablename=''):
 	return found[0]
 
 
+def get_healpix_resolution_degrees(nside):
+	"""0.7 x the mean pixel spacing sqrt(4 pi / (12 nside^2)) of a HEALPix map, in degrees: the
+	largest search radius the reference trusts a pixel and its neighbours to contain
+	(fastskymatch.py:83-88).  Kept for callers of the module; the device pipeline hashes all-sky
+	catalogues into its own declination-band cells and never pixelises with HEALPix."""
+	return 0.7 * (numpy.sqrt(numpy.pi / 3.) / nside) / numpy.pi * 180
+
+
 def crossproduct(radectables, err, logger=None, pairwise_errs=[]):
 	"""All candidate tuples, int64 (M, k), lexicographically sorted, -1 = no counterpart.
 
