@@ -129,6 +129,16 @@ int nwayhip_dist(const double* a_ra, const double* a_dec, const double* b_ra, co
  * (row-major, only i<j read), h_sigma: host array of ncat device pointers. */
 int nwayhip_log_bf(int32_t ncat, int64_t n, const double* const* h_sep, const double* const* h_sigma,
 	double* out, void* stream);
+/* bayesdistance.py:207-240  log_bf_elliptical(separations_ra, separations_dec, pos_errors): per-axis
+ * separations (arcsec; host arrays of ncat*ncat device pointers, only i<j read) and, per catalogue,
+ * the error ellipse as (sigma_x, sigma_y, rho) columns (host arrays of ncat device pointers). */
+int nwayhip_log_bf_elliptical(int32_t ncat, int64_t n, const double* const* h_sep_ra, const double* const* h_sep_dec,
+	const double* const* h_sigma_x, const double* const* h_sigma_y, const double* const* h_rho, double* out, void* stream);
+/* fastskymatch.py:50-74  the two offset columns of dist3d(apos, bpos): longitude and latitude
+ * differences (degrees, a minus b) in the offset frame centred on a; -99 inputs give NaN.
+ * (The separation column of dist3d is nwayhip_dist.) */
+int nwayhip_offsets(const double* a_ra, const double* a_dec, const double* b_ra, const double* b_dec, int64_t n,
+	double* d_lon_deg, double* d_lat_deg, void* stream);
 /* bayesdistance.py:26-32 (mode 0: posterior), :18-23 (mode 1: log_posterior),
  * :35-39 (mode 2: unnormalised_log_posterior) */
 int nwayhip_posterior(int32_t mode, const double* prior, const double* log_bf, int64_t n, double* out, void* stream);

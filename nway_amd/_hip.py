@@ -60,6 +60,9 @@ SYMBOLS = {
 	'nwayhip_device_count': (ctypes.c_int, [ctypes.POINTER(ctypes.c_int)]),
 	'nwayhip_dist': (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _vp, _vp]),
 	'nwayhip_log_bf': (ctypes.c_int, [_i32, _i64, ctypes.POINTER(_vp), ctypes.POINTER(_vp), _vp, _vp]),
+	'nwayhip_log_bf_elliptical': (ctypes.c_int, [_i32, _i64, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp),
+		ctypes.POINTER(_vp), _vp, _vp]),
+	'nwayhip_offsets': (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
 	'nwayhip_posterior': (ctypes.c_int, [_i32, _vp, _vp, _i64, _vp, _vp]),
 	'nwayhip_plan_create': (ctypes.c_int, [ctypes.POINTER(_vp), ctypes.POINTER(MatchParams), ctypes.POINTER(_i64), _i64, _i64]),
 	'nwayhip_plan_destroy': (ctypes.c_int, [_vp]),

@@ -97,10 +97,10 @@ def log_bf(p, s):
 
 # ---------------------------------------------------------------------------------------
 # Elliptical / asymmetric position errors (reference: bayesdistance.py:92-240).
-# Host-side numpy helpers on 2x2 matrices whose entries are arrays ("vectorised": one
-# matrix per table row).  They reduce an elliptical error to the circular formula by
-# rescaling each separation with the error along its direction; the Bayes factor itself is
-# again ``log_bf`` on the device.
+# The 2x2 matrix helpers (entries may be arrays: one matrix per table row) are part of the
+# reference's importable surface and stay plain numpy expressions; ``log_bf_elliptical`` itself --
+# rescaling each separation with the error along its direction, then the circular formula -- is
+# one device kernel.
 # ---------------------------------------------------------------------------------------
 
 def assert_possemdef(M):
@@ -191,19 +191,27 @@ def convert_from_ellipse(a, b, phi):
 
 def log_bf_elliptical(separations_ra, separations_dec, pos_errors):
 	"""log10 Bayes factor for elliptical errors: pos_errors = list of (sigma_ra, sigma_dec, rho)
-	per catalogue; separations given per axis.  Each pair's separation is rescaled by the
-	ratio of the circularised to the directional error, then the circular formula applies."""
-	inverse = [make_invcovmatrix(sx, sy, rho) for sx, sy, rho in pos_errors]
-	circular = [((sx**2 + sy**2) / 2)**0.5 for sx, sy, rho in pos_errors]
-	n = len(inverse)
-	rescaled = [[None] * n for _ in range(n)]
-	for i in range(n):
-		for j in range(i + 1, n):
-			v = (separations_ra[i][j], separations_dec[i][j])
-			length = vector_multiply(v, v)**0.5
-			unit = vector_normalised(v)
-			wi = vector_multiply(apply_vector_left(unit, inverse[i]), unit)
-			wj = vector_multiply(apply_vector_left(unit, inverse[j]), unit)
-			stretch = (circular[i]**2 + circular[j]**2) / (1 / wi + 1 / wj)
-			rescaled[i][j] = length * stretch**-0.5
-	return log_bf(rescaled, circular)
+	per catalogue; separations given per axis (n x n nested sequences, entries with i < j read).
+	Each pair's separation is rescaled by the ratio of the circularised to the directional error,
+	then the circular formula applies (bayesdistance.py:207-240).  One device kernel
+	(``nwayhip_log_bf_elliptical``); entries broadcast against each other."""
+	n = len(pos_errors)
+	if n < 1 or n > _hip.MAXCAT:
+		raise ValueError('log_bf_elliptical supports 1..%d catalogues' % _hip.MAXCAT)
+	pairs = [(i, j) for i in range(n) for j in range(i + 1, n)]
+	columns = [pos_errors[c][m] for c in range(n) for m in range(3)]
+	columns += [separations_ra[i][j] for i, j in pairs] + [separations_dec[i][j] for i, j in pairs]
+	(dev, shape, device) = _on_device(columns)
+	t = _hip.torch()
+	nrows = int(dev[0].shape[0])
+	sx = (ctypes.c_void_p * n)(*[dev[3 * c].data_ptr() for c in range(n)])
+	sy = (ctypes.c_void_p * n)(*[dev[3 * c + 1].data_ptr() for c in range(n)])
+	rho = (ctypes.c_void_p * n)(*[dev[3 * c + 2].data_ptr() for c in range(n)])
+	sra = (ctypes.c_void_p * (n * n))()
+	sdec = (ctypes.c_void_p * (n * n))()
+	for m, (i, j) in enumerate(pairs):
+		sra[i * n + j] = dev[3 * n + m].data_ptr()
+		sdec[i * n + j] = dev[3 * n + len(pairs) + m].data_ptr()
+	out = t.empty(nrows, dtype=t.float64, device=device)
+	_hip.check(_hip.load().nwayhip_log_bf_elliptical(n, nrows, sra, sdec, sx, sy, rho, _hip.ptr(out), _hip.current_stream_ptr(device)))
+	return _finish(out, shape)

@@ -5,38 +5,39 @@ bayesdistance.py:207-240).
 
 The candidate enumeration, separations, radius filter and priors are the device pipeline's
 as for circular errors; only the Bayes factor differs: per pair the tangent-plane offsets
-(d_ra, d_dec) are rescaled by the error along their direction and the circular formula is
-evaluated on the device (``bayesdistance.log_bf``).
+(d_ra, d_dec; device kernel ``nwayhip_offsets``) are rescaled by the error along their direction
+and the circular formula is evaluated (device kernel ``nwayhip_log_bf_elliptical``).  This module
+only selects rows per presence pattern and gathers the error columns.
 
-Parity status: UNPINNED.  The reference computes the offsets with astropy's SkyOffsetFrame,
-which is absent here (and unpinned upstream); ``offsets`` restates that frame (rotation of the
-sphere that puts the first position at the origin) and is checked for self-consistency only.
+Parity status: ``log_bf_elliptical`` pinned (tests/golden/ellmath.npz); the offsets UNPINNED --
+the reference computes them with astropy's SkyOffsetFrame, which is absent here (and unpinned
+upstream); ``nwayhip_offsets`` is the rotation of the sphere that puts the first position at the
+origin, checked against oracle/elliptical_oracle.py and for consistency with the separation.
 """
 from __future__ import division, print_function
 
 import numpy
 
+from . import _hip
 from . import bayesdistance as bayesdist
 
 
 def offsets(a_ra, a_dec, b_ra, b_dec):
 	"""(d_lon, d_lat) in degrees of position b seen from the offset frame centred on a, with the
-	sign convention of fastskymatch.py:66-67 (a minus b).  -99 marks an absent source -> NaN."""
-	a_ra = numpy.where(a_ra == -99, numpy.nan, numpy.asarray(a_ra, dtype=float))
-	a_dec = numpy.where(a_dec == -99, numpy.nan, numpy.asarray(a_dec, dtype=float))
-	b_ra = numpy.where(b_ra == -99, numpy.nan, numpy.asarray(b_ra, dtype=float))
-	b_dec = numpy.where(b_dec == -99, numpy.nan, numpy.asarray(b_dec, dtype=float))
-	dlon = numpy.radians(b_ra - a_ra)
-	lat0, lat = numpy.radians(a_dec), numpy.radians(b_dec)
-	x1 = numpy.cos(lat) * numpy.cos(dlon)
-	y1 = numpy.cos(lat) * numpy.sin(dlon)
-	z1 = numpy.sin(lat)
-	x = x1 * numpy.cos(lat0) + z1 * numpy.sin(lat0)
-	z = -x1 * numpy.sin(lat0) + z1 * numpy.cos(lat0)
-	with numpy.errstate(invalid='ignore'):
-		lon_b = numpy.degrees(numpy.arctan2(y1, x))
-		lat_b = numpy.degrees(numpy.arcsin(numpy.clip(z, -1, 1)))
-	return -lon_b, -lat_b
+	sign convention of fastskymatch.py:66-67 (a minus b).  -99 marks an absent source -> NaN.
+	Device kernel ``nwayhip_offsets``."""
+	arrs = numpy.broadcast_arrays(*[numpy.asarray(x, dtype=float) for x in (a_ra, a_dec, b_ra, b_dec)])
+	shape = arrs[0].shape
+	device = _hip.require_device()
+	t = _hip.torch()
+	dev = [_hip.to_device(numpy.ascontiguousarray(a).reshape(-1), device) for a in arrs]
+	n = int(dev[0].shape[0])
+	d_lon = t.empty(n, dtype=t.float64, device=device)
+	d_lat = t.empty(n, dtype=t.float64, device=device)
+	_hip.check(_hip.load().nwayhip_offsets(_hip.ptr(dev[0]), _hip.ptr(dev[1]), _hip.ptr(dev[2]), _hip.ptr(dev[3]), n,
+		_hip.ptr(d_lon), _hip.ptr(d_lat), _hip.current_stream_ptr(device)))
+	lon, lat = d_lon.cpu().numpy().reshape(shape), d_lat.cpu().numpy().reshape(shape)
+	return (lon, lat) if shape else (float(lon), float(lat))
 
 
 def error_triplets(tables, table_names, pos_errors, idx_columns):
@@ -91,35 +92,46 @@ def log_bf_table(k, idx_columns, sep_ra, sep_dec, errors):
 
 
 def unrelated_associations(k, idx_columns, ncat, sep_ra, sep_dec, errors, dens, dens_plus, log_bf):
-	"""the script's correction (nway.py:366-420) with the elliptical Bayes factor, vectorised
-	over the rows of each primary"""
+	"""the script's correction (nway.py:366-420) with the elliptical Bayes factor: a row lacking two
+	or more catalogues (ncat <= k - 2) gains max(0, best), the best log posterior of a
+	sub-association of its MISSING catalogues found among the richer rows (ncat > 2) of the same
+	primary.  One device evaluation per sub-association pattern over all rows that contain it;
+	the host only selects rows and takes per-primary maxima."""
 	log_bf = log_bf.copy()
+	nrows = len(ncat)
 	prim = idx_columns[0]
 	starts = numpy.flatnonzero(numpy.r_[True, prim[1:] != prim[:-1]])
-	ends = numpy.r_[starts[1:], len(prim)]
-	present = numpy.stack([idx >= 0 for idx in idx_columns], axis=1)
-	for lo, hi in zip(starts, ends):
-		rows = numpy.arange(lo, hi)
-		cand = rows[ncat[rows] <= k - 2]
-		rich = rows[ncat[rows] > 2]
-		if len(cand) == 0 or len(rich) == 0:
+	group = numpy.repeat(numpy.arange(len(starts)), numpy.diff(numpy.r_[starts, nrows]))
+	code = numpy.zeros(nrows, dtype=numpy.int64)  # bit c-1: secondary catalogue c is present
+	for c in range(1, k):
+		code |= (idx_columns[c] >= 0).astype(numpy.int64) << (c - 1)
+	everything = (1 << (k - 1)) - 1
+	rich = ncat > 2
+	cand = ncat <= k - 2
+	if not cand.any() or not rich.any():
+		return log_bf
+	value = {}  # sub-association -> its log posterior on the rich rows that contain it
+	for sub in range(1, everything + 1):
+		cats = [c for c in range(1, k) if (sub >> (c - 1)) & 1]
+		sel = numpy.flatnonzero(rich & ((code & sub) == sub))
+		if len(cats) < 2 or len(sel) == 0:
 			continue
-		for i in cand:
-			missing = [c for c in range(1, k) if not present[i, c]]
-			# group the richer rows by which of the missing catalogues they contain
-			sub = present[rich][:, missing]
-			best = 0.0
-			for pat in numpy.unique(sub, axis=0):
-				aug = [c for c, on in zip(missing, pat) if on]
-				if len(aug) < 2:
-					continue
-				sel = rich[(sub == pat).all(axis=1)]
-				sra = [[sep_ra[a][b][sel] if a < b else None for b in aug] for a in aug]
-				sdec = [[sep_dec[a][b][sel] if a < b else None for b in aug] for a in aug]
-				errs = [tuple(e[sel] for e in errors[c]) for c in aug]
-				lb = numpy.atleast_1d(bayesdist.log_bf_elliptical(sra, sdec, errs))
-				logpost = lb + numpy.log10(dens[aug[0]] / numpy.prod(dens_plus[aug]))
-				best = max(best, float(logpost.max()))
-			if best > 0:
-				log_bf[i] += best
+		sra = [[sep_ra[a][b][sel] if a < b else None for b in cats] for a in cats]
+		sdec = [[sep_dec[a][b][sel] if a < b else None for b in cats] for a in cats]
+		errs = [tuple(e[sel] for e in errors[c]) for c in cats]
+		v = numpy.full(nrows, -numpy.inf)
+		v[sel] = numpy.atleast_1d(bayesdist.log_bf_elliptical(sra, sdec, errs)) + numpy.log10(dens[cats[0]] / numpy.prod(dens_plus[cats]))
+		value[sub] = v
+	missing = everything & ~code
+	for pattern in numpy.unique(missing[cand]):
+		shared = code & pattern  # what a richer row can contribute to a row with this pattern
+		u = numpy.full(nrows, -numpy.inf)
+		for sub in numpy.unique(shared[rich]):
+			if int(sub) in value:
+				rows = rich & (shared == sub)
+				u[rows] = value[int(sub)][rows]
+		best = numpy.maximum.reduceat(u, starts)
+		rows = cand & (missing == pattern)
+		gain = best[group[rows]]
+		log_bf[rows] += numpy.where(gain > 0, gain, 0.0)
 	return log_bf

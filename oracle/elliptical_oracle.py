@@ -1,0 +1,104 @@
+"""numpy restatement of the reference's elliptical-error arithmetic.
+
+TEST INFRASTRUCTURE ONLY (see oracle/nway_oracle.py): the product evaluates these on the device
+(nwayhip_log_bf_elliptical, nwayhip_offsets); nothing under nway_amd/ imports this module.
+
+  log_bf_elliptical   nwaylib/bayesdistance.py:207-240 (with make_invcovmatrix :191-195,
+                      vector_normalised :160-163, log_bf :64-86), pinned by
+                      tests/golden/ellmath.npz (values computed with the reference)
+  offsets             the two offset columns of dist3d, nwaylib/fastskymatch.py:50-74.
+                      PARITY UNPINNED: the reference calls astropy's SkyOffsetFrame, which is
+                      absent here; this is the rotation of the sphere that puts the first position
+                      at the origin, with the reference's sign (a minus b)
+"""
+import numpy
+
+log_arcsec2rad = numpy.log(3600 * 180 / numpy.pi)
+
+
+def log_bf(p, s):
+	"""bayesdistance.py:64-86"""
+	n = len(s)
+	s = [numpy.asarray(si, dtype=float) for si in s]
+	w = [si**-2. for si in s]
+	norm = (n - 1) * numpy.log(2) + 2 * (n - 1) * log_arcsec2rad
+	wsum = sum(w)
+	slog = sum(numpy.log(wi) for wi in w) - numpy.log(wsum)
+	q = 0
+	for i in range(n):
+		for j in range(i + 1, n):
+			q = q + w[i] * w[j] * numpy.asarray(p[i][j])**2
+	exponent = -q / 2 / wsum
+	return (norm + slog + exponent) * numpy.log10(numpy.e)
+
+
+def log_bf_elliptical(separations_ra, separations_dec, pos_errors):
+	"""bayesdistance.py:207-240"""
+	inverse, circular = [], []
+	for sx, sy, rho in pos_errors:
+		scale = 1.0 / (sx**2 * sy**2 * (1 - rho**2))
+		off = scale * -rho * sx * sy
+		inverse.append(((scale * sy**2, off), (off, scale * sx**2)))
+		circular.append(((sx**2 + sy**2) / 2)**0.5)
+	n = len(inverse)
+	rescaled = [[None] * n for _ in range(n)]
+	for i in range(n):
+		for j in range(i + 1, n):
+			vx, vy = separations_ra[i][j], separations_dec[i][j]
+			length = (vx * vx + vy * vy)**0.5
+			ux = numpy.where(length == 0, 2**-0.5, vx / (length + 1e-300))
+			uy = numpy.where(length == 0, 2**-0.5, vy / (length + 1e-300))
+			w = []
+			for (a, b), (_, d) in (inverse[i], inverse[j]):
+				w.append((ux * a + uy * b) * ux + (ux * b + uy * d) * uy)
+			stretch = (circular[i]**2 + circular[j]**2) / (1 / w[0] + 1 / w[1])
+			rescaled[i][j] = length * stretch**-0.5
+	return log_bf(rescaled, circular)
+
+
+def offsets(a_ra, a_dec, b_ra, b_dec):
+	"""(d_lon, d_lat) in degrees, a minus b, in the offset frame centred on a; -99 -> NaN"""
+	a_ra = numpy.where(a_ra == -99, numpy.nan, numpy.asarray(a_ra, dtype=float))
+	a_dec = numpy.where(a_dec == -99, numpy.nan, numpy.asarray(a_dec, dtype=float))
+	b_ra = numpy.where(b_ra == -99, numpy.nan, numpy.asarray(b_ra, dtype=float))
+	b_dec = numpy.where(b_dec == -99, numpy.nan, numpy.asarray(b_dec, dtype=float))
+	dlon = numpy.radians(b_ra - a_ra)
+	lat0, lat = numpy.radians(a_dec), numpy.radians(b_dec)
+	x1 = numpy.cos(lat) * numpy.cos(dlon)
+	y1 = numpy.cos(lat) * numpy.sin(dlon)
+	z1 = numpy.sin(lat)
+	x = x1 * numpy.cos(lat0) + z1 * numpy.sin(lat0)
+	z = -x1 * numpy.sin(lat0) + z1 * numpy.cos(lat0)
+	with numpy.errstate(invalid='ignore'):
+		lon_b = numpy.degrees(numpy.arctan2(y1, x))
+		lat_b = numpy.degrees(numpy.arcsin(numpy.clip(z, -1, 1)))
+	return -lon_b, -lat_b
+
+
+def unrelated_associations(k, idx_columns, ncat, sep_ra, sep_dec, errors, dens, dens_plus, log_bf_values):
+	"""nway.py:366-420 with the elliptical branch (:402-411), row by row as the script does it"""
+	out = numpy.array(log_bf_values, dtype=float)
+	prim = idx_columns[0]
+	starts = numpy.flatnonzero(numpy.r_[True, prim[1:] != prim[:-1]])
+	ends = numpy.r_[starts[1:], len(prim)]
+	present = numpy.stack([idx >= 0 for idx in idx_columns], axis=1)
+	for lo, hi in zip(starts, ends):
+		for i in range(lo, hi):
+			if not ncat[i] <= k - 2:
+				continue
+			missing = [c for c in range(k) if not present[i, c]]
+			best = 0.0
+			for j in range(lo, hi):
+				if not ncat[j] > 2:
+					continue
+				aug = [c for c in missing if present[j, c]]
+				if len(aug) >= 2:
+					sra = [[numpy.array([sep_ra[a][b][j]]) if a < b else None for b in aug] for a in aug]
+					sdec = [[numpy.array([sep_dec[a][b][j]]) if a < b else None for b in aug] for a in aug]
+					errs = [tuple(numpy.array([e[j]]) for e in errors[c]) for c in aug]
+					logpost = log_bf_elliptical(sra, sdec, errs)[0] + numpy.log10(dens[aug[0]] / numpy.prod(dens_plus[aug]))
+					if logpost > best:
+						best = logpost
+			if best > 0:
+				out[i] += best
+	return out

@@ -110,3 +110,105 @@ def test_cli_elliptical_columns_reduce_to_circular(tmp_path, monkeypatch):
 	assert cli.main(base + ['CHANDRA.fits', ':a2:b2:phi', 'OPT.fits', '0.1', '--out', 'ell2.fits']) == 0
 	e2 = _fits.read_table('ell2.fits')
 	assert len(e2.data) > 100 and np.isfinite(e2.data['p_i']).all()
+
+
+def test_elliptical_oracle_against_reference_values():
+	"""oracle/elliptical_oracle.py (numpy restatement) against values computed with the reference"""
+	import os
+	import sys
+	sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'oracle'))
+	import elliptical_oracle as eo
+	from nway_amd import bayesdistance as bd
+	g = golden('ellmath')
+	nan = np.nan * np.ones(len(g['a']))
+	e = [bd.convert_from_ellipse(g['a' + s], g['b' + s], g['phi' + s]) for s in ('', '2', '3')]
+	dra, ddec = g['dra'], g['ddec']
+	got = eo.log_bf_elliptical([[nan, dra[0], dra[1]], [nan, nan, dra[2]], [nan, nan, nan]],
+		[[nan, ddec[0], ddec[1]], [nan, nan, ddec[2]], [nan, nan, nan]], e)
+	np.testing.assert_allclose(got, g['log_bf_ell3'], rtol=1e-12)
+	got = eo.log_bf_elliptical([[nan, dra[0]], [nan, nan]], [[nan, ddec[0]], [nan, nan]], e[:2])
+	np.testing.assert_allclose(got, g['log_bf_ell2'], rtol=1e-12)
+	# offsets: along a meridian / the equator they are the coordinate differences; their length
+	# is the great-circle separation for small offsets
+	lon, lat = eo.offsets(np.array([10.0, 10.0]), np.array([0.0, 20.0]), np.array([10.5, 10.0]), np.array([0.0, 20.25]))
+	np.testing.assert_allclose(lon, [-0.5, 0.0], atol=1e-12)
+	np.testing.assert_allclose(lat, [0.0, -0.25], atol=1e-12)
+	assert np.isnan(eo.offsets(np.array([-99.0]), np.array([-99.0]), np.array([1.0]), np.array([1.0]))[0]).all()
+
+
+@pytest.mark.gpu
+def test_offsets_gpu_against_oracle():
+	"""nwayhip_offsets (the two offset columns of dist3d) against the numpy restatement, over the
+	whole sphere incl. the poles, the seam and absent sources"""
+	import os
+	import sys
+	sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'oracle'))
+	import elliptical_oracle as eo
+	from nway_amd import elliptical, fastskymatch
+	rng = np.random.RandomState(8)
+	n = 5000
+	a_ra = rng.uniform(0, 360, n)
+	a_dec = np.degrees(np.arcsin(rng.uniform(-1, 1, n)))
+	b_ra = a_ra + rng.normal(0, 1, n) * 10**rng.uniform(-6, 1.5, n)
+	b_dec = np.clip(a_dec + rng.normal(0, 1, n) * 10**rng.uniform(-6, 1.5, n), -90, 90)
+	a_dec[:3] = [90, -90, 89.9999]
+	a_ra[3], b_ra[3] = 359.9999, 0.0001
+	b_ra[4] = b_dec[4] = -99
+	a_ra[5] = a_dec[5] = -99
+	lon, lat = elliptical.offsets(a_ra, a_dec, b_ra, b_dec)
+	elon, elat = eo.offsets(a_ra, a_dec, b_ra, b_dec)
+	np.testing.assert_allclose(lon, elon, rtol=1e-9, atol=1e-12, equal_nan=True)
+	np.testing.assert_allclose(lat, elat, rtol=1e-9, atol=1e-12, equal_nan=True)
+	assert np.isnan(lon[4]) and np.isnan(lat[5])
+	# small offsets: their length is the great-circle separation (dist3d's first column)
+	sep, dra, ddec = fastskymatch.dist3d((a_ra[6:], a_dec[6:]), (b_ra[6:], b_dec[6:]))
+	small = sep < 0.01
+	np.testing.assert_allclose(np.hypot(dra[small], ddec[small]), sep[small], rtol=1e-5)
+	np.testing.assert_array_equal(dra, lon[6:])
+
+
+@pytest.mark.gpu
+def test_elliptical_correction_against_row_by_row_oracle():
+	"""nway_amd.elliptical.unrelated_associations (one device evaluation per sub-association, per
+	primary maxima) against the script's row-by-row loop restated in oracle/elliptical_oracle.py,
+	on a 4-way table with random ellipses"""
+	import os
+	import sys
+	sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'oracle'))
+	import elliptical_oracle as eo
+	import nway_amd
+	from nway_amd import elliptical
+	from goldenutil import cat
+	g = golden('kway')
+	k = 4
+	tabs = [cat('T%d' % i, g['k4c_ra%d' % i], g['k4c_dec%d' % i], g['k4c_err%d' % i], g['k4c_area'][0]) for i in range(k)]
+	res = nway_amd.run_match(tabs, 25., 0.7, logger=nway_amd.NullOutputLogger())
+	idx = [res.to_host('idx', c).astype(np.int64) for c in range(k)]
+	ncat = res.to_host('ncat').astype(np.int64)
+	nrows = len(ncat)
+	rng = np.random.RandomState(12)
+	sep_ra = [[None] * k for _ in range(k)]
+	sep_dec = [[None] * k for _ in range(k)]
+	for i in range(k):
+		for j in range(i):
+			def coords(c):
+				return np.where(idx[c] >= 0, tabs[c]['ra'][idx[c]], -99.), np.where(idx[c] >= 0, tabs[c]['dec'][idx[c]], -99.)
+			dra, ddec = elliptical.offsets(*(coords(i) + coords(j)))
+			sep_ra[j][i], sep_dec[j][i] = dra * 3600, ddec * 3600
+	errors = []
+	for c in range(k):
+		n = len(tabs[c]['ra'])
+		a, b, phi = rng.uniform(0.5, 3, n), rng.uniform(0.5, 3, n), rng.uniform(0, np.pi, n)
+		sx, sy, rho = nway_amd.bayesdist.convert_from_ellipse(a, b, phi)
+		pick = lambda v: np.where(idx[c] >= 0, v[idx[c]], -99.)
+		errors.append((pick(sx), pick(sy), np.where(idx[c] >= 0, rho[idx[c]], 0.0)))
+	dens = np.array([len(t['ra']) / t['area'] * 41252.96 for t in tabs])
+	dens_plus = np.array([(len(t['ra']) + 1) / t['area'] * 41252.96 for t in tabs])
+	dens_plus[0] = dens[0]
+	base = elliptical.log_bf_table(k, idx, sep_ra, sep_dec, errors)
+	assert np.isfinite(base).all()
+	got = elliptical.unrelated_associations(k, idx, ncat, sep_ra, sep_dec, errors, dens, dens_plus, base)
+	want = eo.unrelated_associations(k, idx, ncat, sep_ra, sep_dec, errors, dens, dens_plus, base)
+	assert (want != base).sum() > 100
+	np.testing.assert_allclose(got, want, rtol=1e-9, atol=1e-9)
+	res.plan.close()
