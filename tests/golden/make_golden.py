@@ -625,6 +625,8 @@ def gen_mag3():
 		os.chdir(cwd)
 	out.update(checksums(res, names, 'm3_'))
 	out.update(subset_rows(res, names, 23, 'm3_'))
+	out['m3_columns'] = np.array(list(res.columns))            # the frame's layout: names in order,
+	out['m3_dtypes'] = np.array([str(res[c].dtype) for c in res.columns])  # and their dtypes
 	mask = (res['XMM'].values % 23) == 0
 	for b in biases:
 		v = res[b].values

@@ -270,7 +270,11 @@ def test_three_way_magnitude_priors_golden(nw, tmp_path, monkeypatch):
 	g = golden('mag3')
 	monkeypatch.chdir(tmp_path)
 	names = ['XMM', 'OPT', 'IRAC']
-	t = run(nw, mag3_tables(), 20., 0.9, store_mag_hists=False)
+	df = nw.nway_match(mag3_tables(), 20., 0.9, store_mag_hists=False, logger=nw.NullOutputLogger())
+	# the frame's layout: column names in the reference's order, and their dtypes
+	assert list(df.columns) == [str(c) for c in g['m3_columns']]
+	assert [str(df[c].dtype) for c in df.columns] == [str(d) for d in g['m3_dtypes']]
+	t = as_dict(df)
 	assert_checksums_match(t, g, 'm3_', names)
 	rows = g['m3_sub_rows']
 	assert_table_matches(t, g, 'm3_sub_', names, rows=rows)
