@@ -7,12 +7,16 @@ as ``{TABLE}_{column}`` with -99 for absent counterparts, floats are written as 
 unrelated-association correction is the working one (nway.py:366-423), the auto-histogram
 selection indexes its weights by the selected rows (nway.py:471).
 
-Asymmetric / elliptical error columns (``:ra_err:dec_err``, ``:major:minor:angle``) use the
-device pipeline for the candidates and nway_amd/elliptical.py for the Bayes factors (parity
-unpinned: the reference needs astropy's SkyOffsetFrame).
+The script's numerics are reproduced as well (``f32_roundtrip``: its separations pass through a
+float32 FITS column before log_bf squares them; pinned by tests/golden/f32.npz,
+magscript.npz and the script variants of fuzz.npz / kway.npz / sparse.npz).
 
-Not reproduced: the float32 round trip of the separations before log_bf (the
-outputs are float32 anyway), ``--prefilter-pair`` (broken upstream, fastskymatch.py:203).
+Asymmetric / elliptical error columns (``:ra_err:dec_err``, ``:major:minor:angle``) use the
+device pipeline for the candidates and nway_amd/elliptical.py (device kernels for the offsets
+and the elliptical Bayes factor) in float64; the offsets' parity is unpinned: the reference
+needs astropy's SkyOffsetFrame.
+
+Not reproduced: ``--prefilter-pair`` (broken upstream, fastskymatch.py:203).
 """
 from __future__ import division, print_function
 
@@ -102,46 +106,29 @@ def resolve_errors(tables, table_names, pos_errors, match_radius_arcsec):
 def cli_magnitude_bias(mag, magfile, table_names, tables, idx_columns, sep_max, post, mag_include_radius, mag_exclude_radius,
 		minprob, match_radius_arcsec):
 	"""histogram + step function of one ``--mag T:COL file|auto`` option, script flavour
-	(nway.py:434-516); returns (column name, StepFunction, magnitude column)"""
+	(nway.py:434-516); returns (column name, table number, StepFunction, magnitude column)"""
+	from . import magpriors
 	table_name, col_name = mag.split(':', 1)
 	ti = table_names.index(table_name)
-	res = idx_columns[ti]
-	res_defined = res != -1
 	mag_all = numpy.array(tables[ti].data[col_name], dtype=float)
 	mag_all[mag_all == -99] = numpy.nan
-	mask_all = ~numpy.logical_or(numpy.isnan(mag_all), numpy.isinf(mag_all))
 	col = '%s_%s' % (table_name, col_name)
 	if magfile == 'auto':
 		if mag_include_radius is not None:
 			if mag_include_radius >= match_radius_arcsec:
 				print('WARNING: magnitude radius is very large (>= matching radius). Consider using a smaller value.')
-			selection = sep_max < mag_include_radius
-			selection_possible = sep_max < mag_exclude_radius
-			selection_weights = numpy.ones(len(selection))
+			secure, plausible, weights = sep_max < mag_include_radius, sep_max < mag_exclude_radius, numpy.ones(len(sep_max))
 		else:
-			selection = post > minprob
-			selection_weights = post
-			selection_possible = post > 0.01
-		selection = numpy.logical_and(selection, res_defined)
-		selection_weights = selection_weights[selection]
-		selection_possible = numpy.logical_and(selection_possible, res_defined)
-		rows, first_seen = numpy.unique(res[selection], return_index=True)
-		rows_weights = selection_weights[first_seen]
-		assert len(rows) > 1, 'No magnitude values within radius for "%s".' % mag
-		mag_sel = mag_all[rows]
-		rows_possible = numpy.unique(res[selection_possible])
-		mask_others = mask_all.copy()
-		mask_others[rows_possible] = False
-		mask_sel = ~numpy.logical_or(numpy.isnan(mag_sel), numpy.isinf(mag_sel))
+			secure, plausible, weights = post > minprob, post > 0.01, post
+		target, target_weights, field, n_plausible = magpriors.secure_and_field_sources(idx_columns[ti], mag_all, secure, plausible,
+			weights, 'script', mag)
 		print('    magnitude histogram of column "%s": %d secure matches, %d insecure matches and %d secure non-matches of %d total entries (%d valid)'
-			% (col, mask_sel.sum(), len(rows_possible), mask_others.sum(), len(mag_all), mask_all.sum()))
-		bins, hist_sel, hist_all = magnitudeweights.adaptive_histograms(mag_all[mask_others], mag_sel[mask_sel], weights=rows_weights[mask_sel])
+			% (col, len(target), n_plausible, field.sum(), len(mag_all), numpy.isfinite(mag_all).sum()))
+		bins, hist_sel, hist_all = magnitudeweights.adaptive_histograms(mag_all[field], target, weights=target_weights)
 		filename = mag.replace(':', '_') + '_fit.txt'
 		print('    magnitude histogram stored to "%s".' % filename)
-		with open(filename, 'wb') as f:
-			f.write(b'# lo hi selected others\n')
-			numpy.savetxt(f, numpy.transpose([bins[:-1], bins[1:], hist_sel, hist_all]), fmt=['%10.5f'] * 4)
-		if mask_sel.sum() < 100:
+		magpriors.write_histogram(filename, bins, hist_sel, hist_all)
+		if len(target) < 100:
 			print('ERROR: too few secure matches to make a good histogram. If you are sure you want to use this poorly sampled histogram, replace "auto" with the filename. You can also decrease the mag-auto-minprob parameter.')
 			sys.exit(1)
 	else:

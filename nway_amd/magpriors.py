@@ -18,6 +18,42 @@ from . import _hip
 from . import magnitudeweights
 
 
+def secure_and_field_sources(idx, magnitudes, secure, plausible, weights, flavour, label):
+	"""Which sources of a catalogue enter the two histograms of one magnitude column.
+
+	idx: the catalogue's index column of the match table (-1 = absent); secure / plausible: row
+	masks (a secure counterpart; a counterpart that cannot be ruled out); weights: one per row.
+	Returns (magnitudes of the secure counterparts, their weights, mask of the field sources,
+	number of plausible sources).  Field = every source with a finite magnitude that is not a
+	plausible counterpart of anything.
+
+	The weight of a secure counterpart is looked up at the position of its first secure row --
+	a position among the rows that HAVE a counterpart in ``nwaylib.nway_match``
+	(__init__.py:337) and among the SECURE rows in the script (nway.py:471).  Both are kept, as
+	is the script's demand for at least two counterparts (nway.py:477) where the API is content
+	with one (__init__.py:343)."""
+	present = idx != -1
+	secure = numpy.logical_and(secure, present)
+	plausible = numpy.logical_and(plausible, present)
+	pool = weights[secure] if flavour == 'script' else weights[present]
+	sources, first_row = numpy.unique(idx[secure], return_index=True)
+	source_weights = pool[first_row]
+	assert len(sources) > (1 if flavour == 'script' else 0), 'No magnitude values within radius for "%s".' % label
+	target = magnitudes[sources]
+	usable = ~numpy.logical_or(numpy.isnan(target), numpy.isinf(target))
+	plausible_sources = numpy.unique(idx[plausible])
+	field = ~numpy.logical_or(numpy.isnan(magnitudes), numpy.isinf(magnitudes))
+	field[plausible_sources] = False
+	return target[usable], source_weights[usable], field, len(plausible_sources)
+
+
+def write_histogram(filename, bins, hist_sel, hist_all):
+	"""the four-column text file of __init__.py:369-373 / nway.py:497-501"""
+	with open(filename, 'wb') as f:
+		f.write(b'# lo hi selected others\n')
+		numpy.savetxt(f, numpy.transpose([bins[:-1], bins[1:], hist_sel, hist_all]), fmt=['%10.5f'] * 4)
+
+
 def apply_magnitude_biasing(match_tables, table, res, mag_include_radius, mag_exclude_radius,
 		magauto_post_single_minvalue, store_mag_hists, logger):
 	"""returns (table with bias_* columns, device tensor ``total`` = dist_bayesfactor + sum of log10 biases)"""
@@ -29,48 +65,30 @@ def apply_magnitude_biasing(match_tables, table, res, mag_include_radius, mag_ex
 	total = res.column('log_bf_corrected').clone()
 	bias_columns = {}
 	for i, tab in enumerate(match_tables):
-		table_name = tab['name']
 		for magvals, maghist, magname in zip(tab['mags'], tab['maghists'], tab['magnames']):
-			col = '%s_%s' % (table_name, magname)
-			mag = '%s:%s' % (table_name, magname)
+			col = '%s_%s' % (tab['name'], magname)
+			mag = '%s:%s' % (tab['name'], magname)
 			logger.log('Incorporating bias "%s" ...' % mag)
-			res_idx = table[table.columns[i]].values
-			res_defined = res_idx != -1
 			mag_all = magvals
 			mag_all[mag_all == -99] = numpy.nan  # in place, like the reference (:319)
-			mask_all = numpy.isfinite(mag_all)
 			if maghist is None:
 				if mag_include_radius is not None:
-					selection = table['Separation_max'].values < mag_include_radius
-					selection_possible = table['Separation_max'].values < mag_exclude_radius
-					selection_weights = numpy.ones(len(selection))
+					sep_max = table['Separation_max'].values
+					secure, plausible, weights = sep_max < mag_include_radius, sep_max < mag_exclude_radius, numpy.ones(nrows)
 				else:
-					selection = (table['dist_post'] > magauto_post_single_minvalue).values
-					selection_weights = table['dist_post'].values
-					selection_possible = (table['dist_post'] > 0.01).values
-				selection = numpy.logical_and(selection, res_defined)
-				selection_weights = selection_weights[res_defined]
-				selection_possible = numpy.logical_and(selection_possible, res_defined)
-				rows, first_seen = numpy.unique(res_idx[selection], return_index=True)
-				rows_weights = selection_weights[first_seen]
-				assert len(rows) > 0, 'No magnitude values within radius for "%s".' % mag
-				mag_sel = magvals[rows]
-				rows_possible = numpy.unique(res_idx[selection_possible])
-				mask_others = mask_all.copy()
-				mask_others[rows_possible] = False
-				mask_sel = ~numpy.logical_or(numpy.isnan(mag_sel), numpy.isinf(mag_sel))
+					post = table['dist_post'].values
+					secure, plausible, weights = post > magauto_post_single_minvalue, post > 0.01, post
+				target, target_weights, field, n_plausible = secure_and_field_sources(table[table.columns[i]].values, mag_all,
+					secure, plausible, weights, 'api', mag)
 				logger.log('magnitude histogram of column "%s": %d secure matches, %d insecure matches and %d secure non-matches of %d total entries (%d valid)'
-					% (col, mask_sel.sum(), len(rows_possible), mask_others.sum(), len(mag_all), mask_all.sum()))
-				bins, hist_sel, hist_all = magnitudeweights.adaptive_histograms(mag_all[mask_others], mag_sel[mask_sel],
-					weights=rows_weights[mask_sel])
+					% (col, len(target), n_plausible, field.sum(), len(mag_all), numpy.isfinite(mag_all).sum()))
+				bins, hist_sel, hist_all = magnitudeweights.adaptive_histograms(mag_all[field], target, weights=target_weights)
 				if store_mag_hists:
 					filename = mag.replace(':', '_') + '_fit.txt'
 					logger.log('magnitude histogram stored to "%s".' % filename)
-					with open(filename, 'wb') as f:
-						f.write(b'# lo hi selected others\n')
-						numpy.savetxt(f, numpy.transpose([bins[:-1], bins[1:], hist_sel, hist_all]), fmt=['%10.5f'] * 4)
-				if mask_sel.sum() < 100:
-					raise UndersampledException('ERROR: too few secure matches (%d) to make a good histogram. If you are sure you want to use this poorly sampled histogram, replace "auto" with the filename. You can also decrease the mag-auto-minprob parameter.' % mask_sel.sum())
+					write_histogram(filename, bins, hist_sel, hist_all)
+				if len(target) < 100:
+					raise UndersampledException('ERROR: too few secure matches (%d) to make a good histogram. If you are sure you want to use this poorly sampled histogram, replace "auto" with the filename. You can also decrease the mag-auto-minprob parameter.' % len(target))
 			else:
 				logger.log('magnitude histogramming: using user-supplied histogram for "%s"' % (col))
 				bins_lo, bins_hi, hist_sel, hist_all = maghist
