@@ -513,7 +513,7 @@ if __name__ == '__main__' and ('allsky' in sys.argv[1:] or not sys.argv[1:]):
 	gen_allsky()
 
 
-def script_numerics(tables, radius, completeness, prob_ratio_secondary=0.5):
+def script_numerics(tables, radius, completeness, prob_ratio_secondary=0.5, consider_unrelated_associations=True):
 	"""The numbers the SCRIPT nway.py would compute, assembled from the reference's
 	own functions: the separations make the trip through a float32 FITS column
 	(fastskymatch.py:328, nway.py:283-302) before _compute_single_log_bf (== nway.py:327-360) and
@@ -530,7 +530,7 @@ def script_numerics(tables, radius, completeness, prob_ratio_secondary=0.5):
 	ends = np.r_[starts[1:], len(prim)]
 	group_of = np.repeat(np.arange(len(starts)), ends - starts)
 	corrected = log_bf.copy()
-	for i in np.where(ncat <= ncats - 2)[0]:
+	for i in (np.where(ncat <= ncats - 2)[0] if consider_unrelated_associations else []):
 		missing_cats = [k for k, sep in enumerate(sep32[0]) if np.isnan(sep[i])]
 		best_logpost = 0
 		g = group_of[i]
@@ -800,6 +800,13 @@ def gen_magscript():
 			out['%s_sub_bias_%s' % (tag, col)] = v[mask]
 			out['%s_hist_%s' % (tag, col)] = np.frombuffer(texts[col], dtype=np.uint8)
 		print('magscript %s: %d rows, flags %s' % (tag, len(final), np.bincount(final['match_flag'].values)))
+	# the other switches of the command line, without magnitudes: --ignore-unrelated-associations
+	# --prior-completeness 0.9:0.8 --acceptable-prob 0.2 --min-prob 0.05
+	plain = [cat(t['name'], t['ra'], t['dec'], t['error'], t['area']) for t in mag3_tables()]
+	final = script_numerics(plain, 20., np.array([1.0, 0.9, 0.8]), prob_ratio_secondary=0.2, consider_unrelated_associations=False)
+	final = final[~(final['prob_this_match'] < 0.05)]
+	out.update(table_arrays(final, names, 'opts_'))
+	print('magscript opts: %d rows, flags %s' % (len(final), np.bincount(final['match_flag'].values)))
 	save('magscript', **out)
 
 

@@ -477,6 +477,26 @@ def test_cli_magnitude_priors_golden(nw, tmp_path, monkeypatch):
 		for col in ('OPT_R', 'OPT_I', 'IRAC_CH1'):
 			np.testing.assert_allclose(np.asarray(d['bias_' + col], dtype=float)[rows], g['%s_sub_bias_%s' % (tag, col)], rtol=2e-6, err_msg=col)
 			assert open(col + '_fit.txt', 'rb').read() == g['%s_hist_%s' % (tag, col)].tobytes(), col
+	# the other switches, without magnitudes: no correction, completeness per catalogue, a lower
+	# ratio for flag 2, truncation by p_i
+	assert cli.main(['--radius', '20', 'XMM.fits', ':pos_err', 'OPT.fits', '0.1', 'IRAC.fits', '0.5', '--prior-completeness', '0.9:0.8',
+		'--ignore-unrelated-associations', '--acceptable-prob', '0.2', '--min-prob', '0.05', '--out', 'opts.fits']) == 0
+	out = _fits.read_table('opts.fits')
+	d = out.data
+	assert 'dist_bayesfactor_corrected' not in out.names
+	t = {'XMM': np.asarray(d['XMM_ID'], dtype=np.int64)}
+	for n in names[1:]:
+		ids = np.asarray(d[n + '_ID'], dtype=np.int64)
+		t[n] = np.where(ids == -99, -1, ids)
+	for i in range(3):
+		for j in range(i + 1, 3):
+			t['Separation_%s_%s' % (names[i], names[j])] = np.asarray(d['Separation_%s_%s' % (names[j], names[i])], dtype=float)
+	for src, dst in (('Separation_max', 'Separation_max'), ('dist_bayesfactor', 'dist_bayesfactor_uncorrected'), ('dist_bayesfactor', 'dist_bayesfactor'),
+			('dist_post', 'dist_post'), ('p_single', 'p_single'), ('p_any', 'prob_has_match'), ('p_i', 'prob_this_match')):
+		t[dst] = np.asarray(d[src], dtype=float)
+	t['ncat'] = np.asarray(d['ncat'], dtype=np.int64)
+	t['match_flag'] = np.asarray(d['match_flag'], dtype=np.int64)
+	assert_table_matches(t, g, 'opts_', names, rtol=2e-6, atol=1e-9)
 
 
 def test_nwaylib_alias(nw):
