@@ -499,6 +499,33 @@ def test_cli_magnitude_priors_golden(nw, tmp_path, monkeypatch):
 	assert_table_matches(t, g, 'opts_', names, rtol=2e-6, atol=1e-9)
 
 
+def test_input_array_flavours(nw):
+	"""lists, strided views, float32 columns holding exactly representable values and an integer
+	error column give the table of the same numbers as contiguous float64 arrays (the columns are
+	canonicalised to float64 on entry)"""
+	rng = np.random.RandomState(17)
+	n0, n1 = 300, 4000
+	pra = np.round(rng.uniform(30, 30.2, n0) * 4096) / 4096      # exact in float32
+	pdec = np.round(rng.uniform(-10, -9.8, n0) * 4096) / 4096
+	sra = np.round(rng.uniform(30, 30.2, n1) * 4096) / 4096
+	sdec = np.round(rng.uniform(-10, -9.8, n1) * 4096) / 4096
+	perr = rng.randint(1, 4, n0)                                   # integers
+	base = run(nw, [cat('P', pra, pdec, perr.astype(float), 0.04), cat('S', sra, sdec, 0.5 * np.ones(n1), 0.04)], 15., 0.9)
+	two = np.zeros((n1, 2))
+	two[:, 0], two[:, 1] = sra, sdec
+	flavours = [
+		[dict(name='P', ra=list(pra), dec=list(pdec), error=list(perr), area=0.04, mags=[], maghists=[], magnames=[]),
+			dict(name='S', ra=two[:, 0], dec=two[:, 1], error=0.5 * np.ones(n1), area=0.04, mags=[], maghists=[], magnames=[])],
+		[dict(name='P', ra=pra.astype(np.float32), dec=pdec.astype(np.float32), error=perr, area=0.04, mags=[], maghists=[], magnames=[]),
+			dict(name='S', ra=sra.astype(np.float32), dec=sdec.astype(np.float32), error=np.float32(0.5) * np.ones(n1, dtype=np.float32), area=0.04,
+				mags=[], maghists=[], magnames=[])],
+	]
+	for tabs in flavours:
+		t = run(nw, tabs, 15., 0.9)
+		for c in base:
+			np.testing.assert_array_equal(t[c], base[c], err_msg=c)
+
+
 def test_nwaylib_alias(nw):
 	import nwaylib
 	import nwaylib.bayesdistance as bd
