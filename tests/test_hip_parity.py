@@ -645,6 +645,52 @@ def test_repeated_runs_of_one_plan(nw, k, slots):
 	res.plan.close()
 
 
+@pytest.mark.parametrize('k,slots', [(2, 0), (3, 0), (2, -1), (3, -1)])
+def test_one_plan_many_batches(nw, k, slots):
+	"""the production pattern: ONE plan and workspace, a different batch of primaries (same
+	count) every step against resident secondaries.  Cells registered by earlier batches stay in
+	the never-cleared table under older epochs and must be invisible: every batch gives the table
+	a fresh plan gives"""
+	from nway_amd import _hip
+	rng = np.random.RandomState(41)
+	n0 = 15000
+	sky = lambda n: (rng.uniform(0, 360, n), np.degrees(np.arcsin(rng.uniform(-1, 1, n))))
+	secs = [cat('B', *sky(150000), 0.3 * np.ones(150000), 41252.96), cat('C', *sky(100000), 0.5 * np.ones(100000), 41252.96)][:k - 1]
+	batches = []
+	for b in range(4):
+		# every batch sits on counterparts of a different slice of the secondaries; batch 3 repeats
+		# the positions of batch 0 shifted by less than a cell, so that it meets batch 0's stale cells
+		if b < 3:
+			src = secs[0]
+			lo = b * n0
+			ra = (src['ra'][lo:lo + n0] + rng.normal(0, 1, n0) / 3600.) % 360
+			dec = np.clip(src['dec'][lo:lo + n0] + rng.normal(0, 1, n0) / 3600., -90, 90)
+		else:
+			ra = (batches[0]['ra'] + 2.0 / 3600.) % 360
+			dec = batches[0]['dec']
+		batches.append(cat('A', ra, dec, rng.uniform(0.5, 2, n0), 41252.96))
+	snap = lambda r: dict(rows=int(r.plan.read_status()[_hip.ST_ROWS]), idx=r.plan.cols['idx'][k - 1][:r.nrows].cpu().numpy().copy(),
+		p_i=r.plan.cols['p_i'][:r.nrows].cpu().numpy().copy(), flag=r.plan.cols['match_flag'][:r.nrows].cpu().numpy().copy())
+	fresh = []
+	for bt in batches:
+		r = nw.run_match([bt] + secs, 10., 0.9, link_slots=slots, logger=nw.NullOutputLogger())
+		fresh.append(snap(r))
+		r.plan.close()
+	res = nw.run_match([batches[0]] + secs, 10., 0.9, link_slots=slots, logger=nw.NullOutputLogger())
+	sec_cats = [_hip.DeviceCatalogue(t['ra'], t['dec'], np.asarray(t['error'], dtype=float), res.plan.device) for t in secs]
+	for rep in range(2):
+		for b, bt in enumerate(batches):
+			prim = _hip.DeviceCatalogue(bt['ra'], bt['dec'], np.asarray(bt['error'], dtype=float), res.plan.device)
+			res.plan.enqueue([prim] + sec_cats)
+			st = res.plan.read_status()
+			assert int(st[_hip.ST_FLAGS]) == 0
+			res.nrows = int(st[_hip.ST_ROWS])
+			got = snap(res)
+			for key in got:
+				np.testing.assert_array_equal(got[key], fresh[b][key], err_msg='batch %d, %s' % (b, key))
+	res.plan.close()
+
+
 def test_cell_table_overflow_grows_the_table(nw):
 	"""a cell table that is too small for the registrations (sources piled up on a pole need many
 	cells each) is flagged and the run repeated with a larger one: same table as a roomy run"""
