@@ -190,8 +190,12 @@ def main():
 	t0 = time.perf_counter()
 	for _ in range(args.steps):
 		step()
-	barrier()
+	# a rank's clock stops when ITS K steps have finished on the device; the closing barrier follows,
+	# and the reported time is the maximum over the ranks (below) -- the moment the slowest rank was
+	# done, without the latency of the barrier collective itself
+	torch.cuda.synchronize(device)
 	elapsed = time.perf_counter() - t0
+	barrier()
 	launches, ms = [0] * _hip.STAGES, [0.0] * _hip.STAGES
 	for pl in plans:
 		n_, ms_ = pl.profile_read()
