@@ -7,7 +7,7 @@ import sys
 import numpy as np
 import pytest
 
-from goldenutil import ROOT, RTOL, ATOL, cat
+from goldenutil import ROOT, RTOL, ATOL, atol_for, cat
 
 sys.path.insert(0, os.path.join(ROOT, 'oracle'))
 import nway_oracle as orc  # noqa: E402
@@ -32,7 +32,7 @@ def compare(nw, tabs, radius, completeness, correction, f32=False):
 			c = 'Separation_%s_%s' % (names[i], names[j])
 			np.testing.assert_allclose(got[c].values, want[c], rtol=RTOL, atol=1e-9, equal_nan=True)
 	for c in FLOATS:
-		np.testing.assert_allclose(got[c].values, want[c], rtol=RTOL, atol=ATOL, err_msg=c)
+		np.testing.assert_allclose(got[c].values, want[c], rtol=RTOL, atol=atol_for(c), err_msg=c)
 	# flags: identical unless two p_i of one primary are equal to within rounding (documented)
 	if not (got['match_flag'].values == want['match_flag']).all():
 		bad = np.flatnonzero(got['match_flag'].values != want['match_flag'])

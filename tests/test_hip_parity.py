@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 
 from goldenutil import (ROOT, golden, ell_tables, xmm_tables, mag_tables, assert_table_matches,
-	assert_checksums_match, idx_hash, cat, RTOL, ATOL)
+	assert_checksums_match, idx_hash, cat, RTOL, ATOL, atol_for)
 
 sys.path.insert(0, os.path.join(ROOT, 'oracle'))
 import nway_oracle as orc  # noqa: E402
@@ -338,7 +338,7 @@ def oracle_vs_hip(nw, tabs, radius, completeness, names, oracle=orc, **kw):
 			c = 'Separation_%s_%s' % (names[i], names[j])
 			np.testing.assert_allclose(t[c], o[c], rtol=RTOL, atol=1e-9, equal_nan=True)
 	for c in ('Separation_max', 'dist_bayesfactor_uncorrected', 'dist_bayesfactor', 'dist_post', 'p_single', 'prob_has_match', 'prob_this_match'):
-		np.testing.assert_allclose(t[c], o[c], rtol=RTOL, atol=ATOL, err_msg=c)
+		np.testing.assert_allclose(t[c], o[c], rtol=RTOL, atol=atol_for(c), err_msg=c)
 	return t
 
 

@@ -51,5 +51,5 @@ for seed in range(lo, hi):
 		print('seed %d ok: k=%d n0=%d ns=%d lambda=%.3f %s rows=%d' % (seed, k, n0, ns, lam, 'sky' if whole_sky else 'patch', len(t['ncat'])))
 	except AssertionError as e:
 		bad.append(seed)
-		print('seed %d FAILED (k=%d n0=%d ns=%d lambda=%.3f): %s' % (seed, k, n0, ns, lam, str(e).strip().splitlines()[0][:200]))
+		print('seed %d FAILED (k=%d n0=%d ns=%d lambda=%.3f): %s' % (seed, k, n0, ns, lam, " | ".join(str(e).strip().splitlines()[:12])[:900]))
 print('%d configurations, %d rows, %d failures %s in %.0f s' % (hi - lo, rows, len(bad), bad, time.time() - t0))
