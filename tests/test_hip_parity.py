@@ -691,6 +691,30 @@ def test_one_plan_many_batches(nw, k, slots):
 	res.plan.close()
 
 
+def test_row_capacity_overflow_before_the_last_expansion_level(nw, monkeypatch):
+	"""a first guess of the row capacity that is already too small for an INTERMEDIATE level of the
+	breadth-first expansion (k >= 4): that run must end quietly with the overflow flag -- it used
+	to hand the next level an item count beyond its buffers, a memory fault once the guess was
+	off by more than the slack behind them (tools/dev/soak_mid.py, k = 6) -- and the repeat with
+	more room gives the table of a roomy first run"""
+	g = golden('kway')
+	for tag, k in (('k6', 6), ('k8', 8)):
+		names = ['T%d' % i for i in range(k)]
+		tabs = [cat(names[i], g['%s_ra%d' % (tag, i)], g['%s_dec%d' % (tag, i)], g['%s_err%d' % (tag, i)], g[tag + '_area'][0]) for i in range(k)]
+		comp = g[tag + '_completeness']
+		comp = float(comp[0]) if len(comp) == 1 else comp
+		radius = float(g[tag + '_radius'][0])
+		want = run(nw, tabs, radius, comp, unrelated_associations='cli')
+		small = len(want['ncat']) // 3  # levels 3.. of the expansion already exceed it
+		roomy = nw._estimate_capacities
+		monkeypatch.setattr(nw, '_estimate_capacities', lambda *a, **kw: (roomy(*a, **kw)[0], small))
+		got = run(nw, tabs, radius, comp, unrelated_associations='cli')
+		monkeypatch.setattr(nw, '_estimate_capacities', roomy)
+		assert len(got['ncat']) == len(want['ncat'])
+		for c in want:
+			np.testing.assert_array_equal(got[c], want[c], err_msg=c)
+
+
 def test_cell_table_overflow_grows_the_table(nw):
 	"""a cell table that is too small for the registrations (sources piled up on a pole need many
 	cells each) is flagged and the run repeated with a larger one: same table as a roomy run"""

@@ -2,7 +2,7 @@
 neighbours per primary from 0.01 to a few, patches and the whole sky, k = 2..4) against the C
 oracle -- covers the fused sparse kernels, their fall-back and the general path at sizes where
 workgroup regions, scans and look-back chains are long
-    python tools/dev/soak_mid.py 0 40        (on the GPU box)
+    python tools/dev/soak_mid.py 0 40        (on the GPU box; SOAK_KMAX=6 for up to six catalogues)
 """
 import os
 import sys
@@ -20,10 +20,10 @@ lo, hi = int(sys.argv[1]), int(sys.argv[2])
 bad, t0, rows = [], time.time(), 0
 for seed in range(lo, hi):
 	rng = np.random.default_rng(5000 + seed)
-	k = int(rng.integers(2, 5))
+	k = int(rng.integers(2, int(os.environ.get('SOAK_KMAX', '4')) + 1))
 	n0 = int(10 ** rng.uniform(3, 4.7))
 	radius = float(rng.choice([2.0, 5.0, 10.0, 20.0]))
-	lam = 10 ** rng.uniform(-2, 0.7 if k == 2 else 0.3)     # chance neighbours per primary and catalogue
+	lam = 10 ** rng.uniform(-2, 0.7 if k == 2 else (0.3 if k < 5 else -0.5))     # chance neighbours per primary and catalogue
 	whole_sky = seed % 3 == 0
 	if whole_sky:
 		area = 41252.96
@@ -45,6 +45,8 @@ for seed in range(lo, hi):
 		tabs.append(cat('S%d' % c, ra[order] % 360 if whole_sky else ra[order], dec[order], float(rng.uniform(0.2, 1.0)) * np.ones(ns), area))
 	names = [t['name'] for t in tabs]
 	kw = dict(correction='cli') if (k > 2 and seed % 2 == 0) else {}
+	if os.environ.get('SOAK_CORR') == 'api':
+		kw = {}
 	try:
 		t = tp.oracle_vs_hip(nw, tabs, radius, float(rng.choice([1.0, 0.9, 0.6])), names, oracle=tp.orc_c, **kw)
 		rows += len(t['ncat'])
