@@ -151,12 +151,12 @@ def main():
 		sizes = [c.n for c in cats]
 		# settle capacities with one untimed run
 		cap_pairs, cap_rows = nway_amd._estimate_capacities(sizes, [SKY_AREA, SKY_AREA], args.radius, scheme, True)
-		plan, st = _hip.run_plan(sizes, params, cats, cap_pairs, cap_rows, device)
+		plan, st = _hip.run_plan(sizes, params, cats, cap_pairs, cap_rows, device, lean=True)
 		rows_per_step = int(st[_hip.ST_ROWS])
 		# every step is a complete, independent pass; with --streams S the steps alternate over S
 		# pipelines (workspace + output table + HIP stream each) so that the latency-bound stages of
 		# one pass overlap the HBM-bound sweep of another
-		plans = [plan] + [_hip.MatchPlan(sizes, params, plan.cap_pairs, plan.cap_rows, device) for _ in range(args.streams - 1)]
+		plans = [plan] + [_hip.MatchPlan(sizes, params, plan.cap_pairs, plan.cap_rows, device, lean=True) for _ in range(args.streams - 1)]
 		streams = [torch.cuda.Stream(device=device) for _ in plans] if len(plans) > 1 else [None]
 		counter = [0]
 

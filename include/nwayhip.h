@@ -72,11 +72,13 @@ typedef struct nwayhip_match_params {
 	int32_t correction;                  /* NWAYHIP_CORRECTION_* */
 	int32_t finalize;                    /* 1: also run the per-primary group statistics with
 	                                        total = dist_bayesfactor (no magnitude biases) */
-	int32_t link_slots;                  /* sparse fast path (any number of catalogues): the links of every
+	int32_t link_slots;                  /* sparse path (any number of catalogues): the links of every
 	                                        secondary catalogue are kept in this many fixed slots per primary
-	                                        and everything after them is fused into one launch.  0 = decide
-	                                        from the densities (8 slots if every catalogue expects < 0.5
-	                                        chance neighbours per primary), -1 = never, > 0 = force */
+	                                        (at most 8), found by the sweep itself, and everything after them
+	                                        is fused into one launch.  0 = decide from the densities (8 slots
+	                                        if every catalogue expects < 0.5 chance neighbours per primary and
+	                                        the primaries' cells fit the direct-mapped table), -1 = never,
+	                                        > 0 = force where possible */
 	double err_deg;                      /* cell size: match_radius / 60. / 60 (__init__.py:128) */
 	double radius_arcsec;                /* match_radius */
 	double prob_ratio_secondary;         /* __init__.py:33 */
@@ -105,7 +107,7 @@ typedef struct nwayhip_table {
 	int8_t* ncat;
 	double* log_bf;                      /* dist_bayesfactor_uncorrected */
 	double* log_bf_corrected;            /* dist_bayesfactor (== log_bf unless correction CLI); may be NULL */
-	double* prior;
+	double* prior;                       /* may be NULL where nwayhip_plan_link_slots() says so */
 	double* dist_post;
 	double* p_single;                    /* finalize only */
 	double* p_any;                       /* prob_has_match */
@@ -156,6 +158,11 @@ int nwayhip_plan_destroy(nwayhip_plan* plan);
 size_t nwayhip_plan_workspace_bytes(const nwayhip_plan* plan);
 /* slots of the plan's cell table (what to multiply when NWAYHIP_FLAG_REG_OVERFLOW comes back) */
 int64_t nwayhip_plan_table_slots(const nwayhip_plan* plan);
+/* link slots per primary the plan settled on: > 0 = the sparse path runs (direct-mapped cell table,
+ * probe inside the sweep, fused tail), 0 = the general path.  On the sparse path with finalize the
+ * table's `prior` column may be NULL (nothing reads it after the fused tail); log_bf_corrected may
+ * be NULL on every path unless the correction is NWAYHIP_CORRECTION_CLI (it then equals log_bf). */
+int32_t nwayhip_plan_link_slots(const nwayhip_plan* plan);
 /* Enqueue the whole pipeline on `stream`.  d_status: device int64[NWAYHIP_STATUS_WORDS].
  * The workspace's contents may be arbitrary the first time a plan sees it (the plan clears what
  * it needs); between runs of the same plan on the same workspace they must be left alone (by

@@ -134,8 +134,9 @@ class MatchResult(object):
 
 def run_match(match_tables, match_radius, prior_completeness=1.0, prob_ratio_secondary=0.5,
 		radius_filter=True, correction=_hip.CORRECTION_NONE, finalize=True, scheme=None, device=None,
-		logger=None, sphere_cell_factor=0.0, bitmap_bits=0, err_deg=None, link_slots=0, table_slots=0, f32_roundtrip=False):
-	"""Upload the catalogues and run the whole HIP pipeline once; returns a MatchResult."""
+		logger=None, sphere_cell_factor=0.0, bitmap_bits=0, err_deg=None, link_slots=0, table_slots=0, f32_roundtrip=False, lean=False):
+	"""Upload the catalogues and run the whole HIP pipeline once; returns a MatchResult.
+	lean: see ``_hip.MatchPlan`` (columns nobody reads afterwards are not materialised)."""
 	logger = logger or NullOutputLogger()
 	device = _hip.require_device(device)
 	ncats = len(match_tables)
@@ -158,7 +159,7 @@ def run_match(match_tables, match_radius, prior_completeness=1.0, prob_ratio_sec
 	cats = [_hip.DeviceCatalogue(ra, dec, numpy.asarray(t['error'], dtype=float), device) for (ra, dec), t in zip(ratables, match_tables)]
 	sizes = [c.n for c in cats]
 	cap_pairs, cap_rows = _estimate_capacities(sizes, [t['area'] * 1.0 for t in match_tables], match_radius, scheme, radius_filter)
-	plan, status = _hip.run_plan(sizes, params, cats, cap_pairs, cap_rows, device)
+	plan, status = _hip.run_plan(sizes, params, cats, cap_pairs, cap_rows, device, lean=lean)
 	return MatchResult(plan, status, [t['name'] for t in match_tables])
 
 
@@ -225,7 +226,7 @@ def nway_match(match_tables, match_radius, prior_completeness,
 		raise EmptyResultException('No matches.')  # nothing can create a bucket (fastskymatch.py:131)
 	logger.log('Computing distance-based probabilities ...')
 	res = run_match(match_tables, match_radius, prior_completeness, prob_ratio_secondary,
-		correction=correction, finalize=not has_mags, device=device, logger=logger, f32_roundtrip=f32_roundtrip)
+		correction=correction, finalize=not has_mags, device=device, logger=logger, f32_roundtrip=f32_roundtrip, lean=not has_mags)
 	if not res.nrows > 0:
 		raise EmptyResultException('No matches.')
 	logger.log('matching: %6d matches after filtering by search radius' % res.nrows)

@@ -68,6 +68,7 @@ SYMBOLS = {
 	'nwayhip_plan_destroy': (ctypes.c_int, [_vp]),
 	'nwayhip_plan_workspace_bytes': (ctypes.c_size_t, [_vp]),
 	'nwayhip_plan_table_slots': (ctypes.c_int64, [_vp]),
+	'nwayhip_plan_link_slots': (ctypes.c_int32, [_vp]),
 	'nwayhip_match_enqueue': (ctypes.c_int, [_vp, ctypes.POINTER(Catalogue), _vp, ctypes.c_size_t, ctypes.POINTER(Table), _vp, _vp]),
 	'nwayhip_plan_profile': (ctypes.c_int, [_vp, ctypes.c_uint32]),
 	'nwayhip_plan_profile_read': (ctypes.c_int, [_vp, ctypes.POINTER(_i64), ctypes.POINTER(_dbl)]),
@@ -205,7 +206,10 @@ class MatchPlan(object):
 	def table_slots(self):
 		return self._table_slots
 
-	def __init__(self, sizes, params, cap_pairs, cap_rows, device):
+	def __init__(self, sizes, params, cap_pairs, cap_rows, device, lean=False):
+		"""lean: allocate only the columns somebody reads afterwards -- ``log_bf_corrected`` is the
+		``log_bf`` tensor itself unless the script's correction runs, and ``prior`` is left out on
+		the sparse path with finalize (the fused tail consumes it in registers)"""
 		t = torch()
 		self.lib = load()
 		self.device = require_device(device)
@@ -220,6 +224,14 @@ class MatchPlan(object):
 		self.handle = handle
 		self.workspace_bytes = int(self.lib.nwayhip_plan_workspace_bytes(handle))
 		self._table_slots = int(self.lib.nwayhip_plan_table_slots(handle))
+		self.link_slots = int(self.lib.nwayhip_plan_link_slots(handle))
+		self.sparse = self.link_slots > 0
+		self.lean = bool(lean)
+		skip = set()
+		if lean and params.correction == CORRECTION_NONE:
+			skip.add('log_bf_corrected')
+		if lean and self.sparse and params.finalize:
+			skip.add('prior')
 		with t.cuda.device(self.device):
 			self.workspace = t.empty(self.workspace_bytes + 256, dtype=t.uint8, device=self.device)
 			self.status = t.zeros(STATUS_WORDS, dtype=t.int64, device=self.device)
@@ -229,7 +241,7 @@ class MatchPlan(object):
 			self.cols['idx'] = [t.empty(cap, dtype=t.int32, device=self.device) for _ in range(self.ncat)]
 			self.cols['sep'] = [f64() for _ in pair_columns(self.ncat)]
 			for name in ('sep_max', 'log_bf', 'log_bf_corrected', 'prior', 'dist_post', 'p_single', 'p_any', 'p_i'):
-				self.cols[name] = f64()
+				self.cols[name] = None if name in skip else f64()
 			self.cols['ncat'] = t.empty(cap, dtype=t.int8, device=self.device)
 			self.cols['match_flag'] = t.empty(cap, dtype=t.int8, device=self.device)
 			self.cols['group_start'] = t.empty(self.sizes[0] + 1, dtype=t.int64, device=self.device)
@@ -240,7 +252,9 @@ class MatchPlan(object):
 		for p in range(len(self.cols['sep'])):
 			tab.sep[p] = self.cols['sep'][p].data_ptr()
 		for name in ('sep_max', 'ncat', 'log_bf', 'log_bf_corrected', 'prior', 'dist_post', 'p_single', 'p_any', 'p_i', 'match_flag', 'group_start'):
-			setattr(tab, name, self.cols[name].data_ptr())
+			setattr(tab, name, self.cols[name].data_ptr() if self.cols[name] is not None else None)
+		if 'log_bf_corrected' in skip:
+			self.cols['log_bf_corrected'] = self.cols['log_bf']  # the same values: one tensor
 		self.table_struct = tab
 		ws = self.workspace.data_ptr()
 		self.ws_ptr = (ws + 255) // 256 * 256
@@ -304,13 +318,20 @@ def make_params(ncat, scheme, radius_arcsec, err_deg, dens, dens_plus, prior_tab
 	return p
 
 
-def run_plan(sizes, params, catalogues, cap_pairs, cap_rows, device, max_retries=6):
+def run_plan(sizes, params, catalogues, cap_pairs, cap_rows, device, max_retries=6, lean=False):
 	"""enqueue, synchronise, grow the capacities on overflow; returns (plan, status)"""
 	for attempt in range(max_retries):
-		plan = MatchPlan(sizes, params, cap_pairs, cap_rows, device)
+		plan = MatchPlan(sizes, params, cap_pairs, cap_rows, device, lean=lean)
 		plan.enqueue(catalogues)
 		st = plan.read_status()
 		flags = int(st[ST_FLAGS])
+		if flags & FLAG_REG_OVERFLOW and plan.sparse:
+			# the direct-mapped table of the sparse path has a fixed size and bounded displacement:
+			# primaries piled up in a few cells go to the general path
+			params.link_slots = -1
+			plan.close()
+			del plan
+			continue
 		if flags & FLAG_REG_OVERFLOW:
 			# the cell table is sized for the expected registrations per primary; catalogues piled
 			# up near a pole need more: come back with a larger table (bounded)

@@ -2,13 +2,22 @@
 //
 // Pipeline (one nwayhip_match_enqueue = everything below on one stream, no host sync):
 //
+// SPARSE inputs (every secondary catalogue expects < 0.5 chance neighbours per primary), 3 launches:
+//   register   primaries -> direct-mapped cell table: ONE atomic per cell (the occupancy bit is
+//              the slot claim), 64-byte record + tag byte by plain stores          [sparse.inc]
+//   sweep      stream ra/dec of the secondary catalogue(s) once (16 B per lane per column),
+//              occupancy bitmap in LDS, one tag word from L2; every workgroup then probes its
+//              own survivors: record line -> Vincenty -> link in the primary's slots
+//                                                              [front.inc, HBM bound]
+//   tail       single-pass scan over the primaries' row counts + rows + group statistics
+//                                                              [tail2.inc, tailk.inc]
+// GENERAL path:
 //   clear+register  primaries -> cell table (16-byte slots) + fine filter (L2) + coarse filter
 //              (LDS copy) + per-primary lon / sin,cos lat                      [front.inc]
-//   sweep_c    stream ra/dec of secondary catalogue c once (16 B/lane nontemporal loads),
-//              LDS coarse filter, 1 bit of the L2 filter, per-wave LDS staging   [HBM bound]
+//   sweep_c    the same streaming kernel, survivors into per-workgroup regions
 //   pairs_c    survivors -> cell table -> Vincenty separation -> (p, s, sep) links
 //   lists_c    links grouped per primary (scan + scatter)            [scan.inc, lists.inc]
-//   k == 2:    finish2 = order + rows + group statistics in one launch     [finish2.inc]
+//   k == 2:    rows (row-parallel) + group statistics                     [finish2.inc]
 //   k >= 3:    segment order, breadth-first tuple expansion (count -> scan -> fill, rows stay
 //              lexicographic), rows kernel, optional correction, groups  [expand.inc, rows.inc]
 //
@@ -31,6 +40,7 @@
 #pragma clang fp contract(off)
 
 #include "common.inc"
+#include "sparse.inc"
 #include "front.inc"
 #include "scan.inc"
 #include "lists.inc"

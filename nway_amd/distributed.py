@@ -172,7 +172,7 @@ class ShardedMatch(object):
 			self.cats.append(_hip.DeviceCatalogue(t['ra'], t['dec'], t['error'], self.device))
 		sizes = [c.n for c in self.cats]
 		cap_pairs, cap_rows = nway_amd._estimate_capacities(sizes, [t['area'] * 1.0 for t in tables], self.match_radius, scheme, True)
-		self.plan, self.status = _hip.run_plan(sizes, self.params, self.cats, cap_pairs, cap_rows, self.device)
+		self.plan, self.status = _hip.run_plan(sizes, self.params, self.cats, cap_pairs, cap_rows, self.device, lean=True)
 
 	# -- per batch -----------------------------------------------------------------------
 	def step(self):

@@ -10,6 +10,7 @@ import nway_oracle as _np_oracle
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB = os.path.join(HERE, '_build', 'libnwayoracle.so')
+LIB_OMP = os.path.join(HERE, '_build', 'libnwayoracle_omp.so')  # the same source with -fopenmp
 MAXCAT, MAXPAIR = 8, 28
 
 
@@ -23,20 +24,32 @@ class Table(ctypes.Structure):
 		('p_i', ctypes.POINTER(ctypes.c_double)), ('match_flag', ctypes.POINTER(ctypes.c_int8))]
 
 
-_lib = None
+_libs = {}
 
 
-def load(build=True):
-	global _lib
-	if _lib is None:
+def load(build=True, omp=False):
+	"""the one-thread library, or (omp=True) the OpenMP build of the same source"""
+	if omp not in _libs:
+		path = LIB_OMP if omp else LIB
 		src = os.path.join(HERE, 'nway_oracle.c')
-		if build and (not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(src)):
+		if build and (not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src)):
 			subprocess.check_call(['make', '-s', '-C', HERE])
-		_lib = ctypes.CDLL(LIB)
-		_lib.nwayo_match.restype = ctypes.c_int
-		_lib.nwayo_dist.restype = ctypes.c_double
-		_lib.nwayo_dist.argtypes = [ctypes.c_double] * 4
-	return _lib
+		lib = ctypes.CDLL(path)
+		lib.nwayo_match.restype = ctypes.c_int
+		lib.nwayo_dist.restype = ctypes.c_double
+		lib.nwayo_dist.argtypes = [ctypes.c_double] * 4
+		lib.nwayo_threads.restype = ctypes.c_int
+		lib.nwayo_set_threads.argtypes = [ctypes.c_int]
+		_libs[omp] = lib
+	return _libs[omp]
+
+
+def host_cores():
+	"""cores this process may run on"""
+	try:
+		return len(os.sched_getaffinity(0))
+	except AttributeError:
+		return os.cpu_count() or 1
 
 
 def _copy(ptr, n, dtype):
@@ -46,9 +59,15 @@ def _copy(ptr, n, dtype):
 
 
 def nway_match(match_tables, match_radius, prior_completeness, prob_ratio_secondary=0.5, correction='api',
-		scheme=None, radius_filter=True, err_deg=None, f32_roundtrip=False):
-	"""columns as nway_oracle.nway_match; additionally '_tests' (separation evaluations)"""
-	lib = load()
+		scheme=None, radius_filter=True, err_deg=None, f32_roundtrip=False, threads=1):
+	"""columns as nway_oracle.nway_match; additionally '_tests' (separation evaluations).
+	threads: 1 = the plain library; n > 1 (or 0 = all the cores this process may use) = the OpenMP
+	build, whose result does not depend on the number of threads"""
+	if threads == 1:
+		lib = load()
+	else:
+		lib = load(omp=True)
+		lib.nwayo_set_threads(int(threads) if threads > 0 else host_cores())
 	k = len(match_tables)
 	names = [t['name'] for t in match_tables]
 	ras = [numpy.ascontiguousarray(t['ra'], dtype=float) for t in match_tables]

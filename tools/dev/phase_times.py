@@ -1,0 +1,62 @@
+"""development aid: where the time of the sparse path's three kernels goes, from wall-clock stamps
+left by thread 0 of every workgroup (common.inc: dbg_stamp; NWAYHIP_DBG_PTR).
+
+    python tools/dev/phase_times.py            (on the GPU box)
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+dev = torch.device('cuda', 0)
+BLOCKS, STAMPS = 1024, 8
+buf = torch.zeros(3 * BLOCKS * STAMPS, dtype=torch.int64, device=dev)
+os.environ['NWAYHIP_DBG_PTR'] = str(buf.data_ptr())
+import bench  # noqa: E402
+import nway_amd  # noqa: E402
+from nway_amd import _hip  # noqa: E402
+
+n0 = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
+n1 = int(sys.argv[2]) if len(sys.argv) > 2 else 10000000
+primary, secondary = bench.make_workload(n0, n1, 1)
+tables = [primary, secondary]
+log = nway_amd.NullOutputLogger()
+err = 5. / 3600
+scheme = nway_amd.choose_scheme([(t['ra'], t['dec']) for t in tables], err)
+dens, dens_plus = nway_amd._compute_source_densities(tables, log)
+comp = nway_amd._completeness_vector(0.9, 2)
+params = _hip.make_params(2, scheme, 5., err, dens, dens_plus, nway_amd._prior_table(dens, dens_plus, comp))
+cats = [_hip.DeviceCatalogue(t['ra'], t['dec'], np.asarray(t['error'], dtype=float), dev) for t in tables]
+sizes = [c.n for c in cats]
+cap_pairs, cap_rows = nway_amd._estimate_capacities(sizes, [bench.SKY_AREA] * 2, 5., scheme, True)
+plan, st = _hip.run_plan(sizes, params, cats, cap_pairs, cap_rows, dev, lean=True)
+for _ in range(5):
+	plan.enqueue(cats)
+torch.cuda.synchronize()
+names = {0: ('k_register_x', ['start', 'ra/dec + sky_point', 'claims + stores landed', 'end']),
+	1: ('k_sweep', ['start', 'bitmap in LDS', 'wave 0 done streaming', 'all waves done', 'probes landed', 'end']),
+	2: ('k_tail2', ['start', 'cnt/slot/sigma landed', 'block scan', 'lookback', 'rows landed', 'group stats landed'])}
+acc = {}
+for rep in range(10):
+	buf.zero_()
+	plan.enqueue(cats)
+	torch.cuda.synchronize()
+	t = buf.cpu().numpy().reshape(3, BLOCKS, STAMPS)
+	for k, (kname, labels) in names.items():
+		used = t[k][:, 0] > 0
+		tk = t[k][used][:, :len(labels)].astype(np.float64) * 0.01  # 100 MHz -> us
+		t0 = tk[:, 0].min()
+		acc.setdefault(k, []).append((tk - t0, used.sum()))
+for k, (kname, labels) in names.items():
+	rel = np.stack([a for a, _ in acc[k]])  # reps x blocks x stamps
+	print('%s: %d workgroups; us since the first workgroup started (mean over workgroups | latest workgroup), mean of 10 runs' % (kname, acc[k][0][1]))
+	for i, lab in enumerate(labels):
+		print('    %-26s %7.2f | %7.2f' % (lab, rel[:, :, i].mean(), rel[:, :, i].max(axis=1).mean()))
+if len(names) == 3:
+	t = buf.cpu().numpy().reshape(3, BLOCKS, STAMPS).astype(np.float64) * 0.01
+	print('last run: register start -> sweep start %.2f us, sweep start -> tail start %.2f us, tail start -> tail end %.2f us' % (
+		t[1][t[1][:, 0] > 0][:, 0].min() - t[0][t[0][:, 0] > 0][:, 0].min(), t[2][t[2][:, 0] > 0][:, 0].min() - t[1][t[1][:, 0] > 0][:, 0].min(),
+		t[2][t[2][:, 0] > 0][:, 5].max() - t[2][t[2][:, 0] > 0][:, 0].min()))
