@@ -3,7 +3,7 @@
 
     python bench.py --gpus 1 --steps 20 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
+        --master-port P bench.py --gpus N --steps K --warmup W [--scaling weak|strong]
 
 Workload (BASELINE.json configs[2], the "HBM-roofline config"; configs[1] needs the two
 COSMOS catalogues that are missing from the reference checkout): synthetic 2-way match,
@@ -11,19 +11,29 @@ COSMOS catalogues that are missing from the reference checkout): synthetic 2-way
 primaries with a true counterpart ("C3-S").
 
 A step = one pass of the whole hot path over the resident catalogues: primary cell
-registration, secondary sweep, separations, neighbour lists, tuple expansion, Bayes
-factors / priors / posteriors, per-primary p_any / p_i / match_flag.  Inputs are resident
-in HBM when the timed region starts; nothing inside the region synchronises with the host.
+registration, secondary sweep, separations, Bayes factors / priors / posteriors, per-primary
+p_any / p_i / match_flag.  Inputs are resident in HBM when the timed region starts; nothing
+inside the region synchronises with the host.  The steps alternate over --sec-buffers distinct
+copies of the secondary catalogue (3 x 160 MB by default) so that no step finds its stream in
+the 256 MiB Infinity Cache.
 
 metric: candidate Bayes-factor evaluations per second = rows of the match table produced
 per second (one row = one match hypothesis incl. the no-counterpart rows), whole job.
 
-Prints ONE JSON line on rank 0 (contract in the task description) with two extra objects:
+--scaling weak (default): every rank owns --n-primary primaries and matches them against the
+whole secondary catalogue (all-gathered once at set-up); strong: the job is fixed at
+--n-primary x --n-secondary, every rank sweeps a 1/N slice of the secondaries against all the
+primaries and the candidates are routed to the primaries' owners (nway_amd.distributed).
+
+Prints ONE JSON line on rank 0 (contract in the task description) with these extra objects:
   roofline     dominant kernel (the secondary sweep, HBM bound): algorithmic bytes per launch
-               (16 B per secondary: ra + dec read once) / mean launch duration measured with
-               HIP events on the pipeline's stream during the timed region.
-  cpu_baseline the C restatement of the oracle (oracle/nway_oracle.c, "port") timed on this
-               host, 1 thread, on a bounded sample of the same workload.
+               (16 B per secondary: ra + dec read once) / mean launch duration measured with HIP
+               events on the pipeline's stream on every 8th launch of the timed region; plus
+               the WHOLE pass by SURVEY 8(d): pass_bytes / ms_per_step / peak = pass_frac.
+  cpu_baseline the C restatement of the oracle (oracle/nway_oracle.c, "port") timed on this host:
+               all cores (OpenMP build), one core, and the numpy oracle on one thread.
+  check        the table of the last timed step against the CPU table of the same workload.
+  io           host -> device upload of the inputs and device -> host download of the table.
 """
 from __future__ import division, print_function
 
@@ -67,36 +77,97 @@ def make_workload(n_primary, n_secondary, seed, true_fraction=0.8, sigma_seconda
 	return primary, secondary
 
 
-def cpu_baseline(primary, secondary, radius, completeness, sample_secondaries):
-	"""C port of the oracle on a bounded sample (all primaries x the first
-	``sample_secondaries`` secondaries), 1 thread"""
+def pass_bytes(tables, rows):
+	"""algorithmic bytes of one pass, SURVEY.md 8(d): every input column read once (ra, dec, and the
+	positional error where it is a column) + every output column written once (k = 2: 66 B per row,
+	k = 3: 94 B per row)"""
+	k = len(tables)
+	b = 0.0
+	for t in tables:
+		b += len(t['ra']) * (16.0 + (8.0 if np.ndim(t['error']) > 0 else 0.0))
+	per_row = 4 * k + 8 * (k * (k - 1) // 2) + 8 + 1 + 8 * 5 + 1
+	return b + per_row * rows
+
+
+def cpu_baseline(primary, secondary, radius, completeness, numpy_sample):
+	"""the CPU legs of SURVEY 8(d): the C port on all the cores this process may use (OpenMP
+	build of the same source) and on one core, whole workload; the numpy oracle (the like-for-like
+	stand-in of the reference's own numpy path) on one thread, on a bounded sample"""
 	sys.path.insert(0, os.path.join(ROOT, 'oracle'))
 	import nway_oracle_c
-	nway_oracle_c.load()
-	n = min(sample_secondaries, len(secondary['ra']))
-	sec = dict(secondary, ra=secondary['ra'][:n], dec=secondary['dec'][:n], error=secondary['error'] * np.ones(n))
+	n = len(secondary['ra'])
+	sec = dict(secondary, error=secondary['error'] * np.ones(n))
+	cores = nway_oracle_c.host_cores()
+	legs = {}
+	table = None
+	for name, threads in (('all_cores', 0), ('one_core', 1)):
+		if threads == 0 and cores == 1:
+			continue
+		t0 = time.perf_counter()
+		table = nway_oracle_c.nway_match([primary, sec], radius, completeness, threads=threads)
+		dt = time.perf_counter() - t0
+		legs[name] = dict(value=len(table['ncat']) / dt, cores=(cores if threads == 0 else 1), seconds=dt, rows=len(table['ncat']))
+	import nway_oracle
+	m = min(numpy_sample, n)
 	t0 = time.perf_counter()
-	table = nway_oracle_c.nway_match([primary, sec], radius, completeness)
+	tn = nway_oracle.nway_match([primary, dict(sec, ra=sec['ra'][:m], dec=sec['dec'][:m], error=sec['error'][:m])], radius, completeness)
 	dt = time.perf_counter() - t0
-	rows = len(table['ncat'])
-	return dict(value=rows / dt, unit='candidate evaluations/s', cores=1, kind='port',
-		sample='oracle/nway_oracle.c, 1 thread: all %d primaries x first %d secondaries of the same workload, %d rows in %.2f s'
-		% (len(primary['ra']), n, rows, dt),
+	legs['numpy_one_thread'] = dict(value=len(tn['ncat']) / dt, cores=1, seconds=dt, rows=len(tn['ncat']),
+		sample='all %d primaries x first %d secondaries' % (len(primary['ra']), m))
+	best = legs.get('all_cores', legs['one_core'])
+	out = dict(value=best['value'], unit='candidate evaluations/s', cores=best['cores'], kind='port',
+		sample='oracle/nway_oracle.c built with -fopenmp, %d threads (os.sched_getaffinity): the whole workload, %d primaries x %d secondaries, '
+			'%d rows in %.2f s' % (best['cores'], len(primary['ra']), n, best['rows'], best['seconds']),
+		one_core=legs['one_core'], numpy_one_thread=legs['numpy_one_thread'],
 		reference_note='the reference itself (pure Python, one thread; it cannot travel to the GPU box) measured in the build container '
-			'on its own fixtures: 8.4e4 rows/s (tests/elltest 2-way, 37 706 rows in 0.45 s), 5.3e4 rows/s (3-way, 450 435 rows in 8.5 s)'), table
+			'on its own fixtures: 8.4e4 rows/s (tests/elltest 2-way, 37 706 rows in 0.45 s), 5.3e4 rows/s (3-way, 450 435 rows in 8.5 s)')
+	return out, table
+
+
+def table_check(plan, names, cpu_table):
+	"""the device table of the last timed step against the CPU table of the same workload: index
+	columns, ncat and match_flag must be identical, the floating columns within 1e-6 relative"""
+	from nway_amd import _hip
+	m = int(plan.read_status()[_hip.ST_ROWS])
+	out = dict(rows_gpu=m, rows_cpu=len(cpu_table['ncat']))
+	if m != out['rows_cpu']:
+		out['ok'] = False
+		return out
+	ok = True
+	for c, nme in enumerate(names):
+		same = bool(np.array_equal(plan.cols['idx'][c][:m].cpu().numpy().astype(np.int64), cpu_table[nme]))
+		out['idx_%s_equal' % nme] = same
+		ok &= same
+	flag = plan.cols['match_flag'][:m].cpu().numpy().astype(np.int64)
+	out['match_flag_equal'] = bool(np.array_equal(flag, cpu_table['match_flag']))
+	out['match_flag_histogram'] = [int(x) for x in np.bincount(flag, minlength=3)]
+	ok &= out['match_flag_equal']
+	worst = 0.0
+	for src, dst in (('log_bf', 'dist_bayesfactor'), ('dist_post', 'dist_post'), ('p_single', 'p_single'), ('p_any', 'prob_has_match'), ('p_i', 'prob_this_match')):
+		got, want = plan.cols[src][:m].cpu().numpy(), cpu_table[dst]
+		rel = np.abs(got - want) / np.maximum(np.abs(want), 1e-12)
+		rel = np.where(np.abs(got - want) <= 1e-12, 0.0, rel)
+		worst = max(worst, float(np.nanmax(rel)) if m else 0.0)
+	out['max_relative_difference'] = worst
+	ok &= worst <= 1e-6
+	out['ok'] = bool(ok)
+	return out
 
 
 def main():
 	ap = argparse.ArgumentParser()
 	ap.add_argument('--gpus', type=int, default=1)
-	ap.add_argument('--steps', type=int, default=20)
-	ap.add_argument('--warmup', type=int, default=3)
+	ap.add_argument('--steps', type=int, default=40)
+	ap.add_argument('--warmup', type=int, default=6)
 	ap.add_argument('--n-primary', type=int, default=100000)
 	ap.add_argument('--n-secondary', type=int, default=10000000)
 	ap.add_argument('--radius', type=float, default=5.0)
 	ap.add_argument('--completeness', type=float, default=0.9)
 	ap.add_argument('--seed', type=int, default=1)
-	ap.add_argument('--cpu-sample', type=int, default=10000000, help='secondaries in the CPU baseline sample (0 = skip)')
+	ap.add_argument('--scaling', choices=['weak', 'strong'], default='weak')
+	ap.add_argument('--sec-buffers', type=int, default=3, help='distinct device copies of the secondary catalogue the steps alternate over')
+	ap.add_argument('--cpu-sample', type=int, default=1000000, help='secondaries in the numpy leg of the CPU baseline (0 = no CPU baseline at all)')
+	ap.add_argument('--event-every', type=int, default=8, help='every n-th sweep launch of the timed region carries a HIP event pair')
 	ap.add_argument('--profile-stages', action='store_true', help='also time every stage (adds event records to the region)')
 	ap.add_argument('--streams', type=int, default=int(os.environ.get('NWAY_BENCH_STREAMS', '1')),
 		help='independent pipelines (own workspace, own output table, own HIP stream) the steps alternate over')
@@ -126,18 +197,29 @@ def main():
 	device = torch.device('cuda', (local_rank % ngpu) if world > 1 else 0)
 	torch.cuda.set_device(device)
 
-	# weak scaling: every rank owns n_primary primaries (a contiguous row shard of the global
-	# primary catalogue, N x n_primary rows) and loads a 1/world slice of the ONE secondary
-	# catalogue (n_secondary rows in total); the slices are all-gathered once at set-up so that
-	# every GPU holds the whole secondary catalogue, then each step matches the rank's primary
-	# shard against it -- per-GPU work is fixed, no collective on the per-step path.
-	n_sec_local = args.n_secondary // world + (args.n_secondary % world if rank == world - 1 else 0)
-	primary, secondary = make_workload(args.n_primary, n_sec_local, args.seed + 1000 * rank)
-	if world > 1:
+	io = None
+	engine = None
+	strong = args.scaling == 'strong' and world > 1
+	if world > 1 and not strong:
+		# weak scaling: every rank owns n_primary primaries (a contiguous row shard of the global
+		# primary catalogue, N x n_primary rows) and loads a 1/world slice of the ONE secondary
+		# catalogue (n_secondary rows in total); the slices are all-gathered once at set-up so that
+		# every GPU holds the whole secondary catalogue, then each step matches the rank's primary
+		# shard against it -- per-GPU work is fixed, no collective on the per-step path.
+		n_sec_local = args.n_secondary // world + (args.n_secondary % world if rank == world - 1 else 0)
+		primary, secondary = make_workload(args.n_primary, n_sec_local, args.seed + 1000 * rank)
 		from nway_amd import distributed
 		engine = distributed.ShardedMatch(primary, [secondary], args.radius, args.completeness, device)
+	elif strong:
+		# strong scaling: ONE job of n_primary x n_secondary.  Every rank generates the same
+		# catalogues (same seed) and keeps its slice of the secondaries and its shard of the primaries
+		from nway_amd import distributed
+		primary, secondary = make_workload(args.n_primary, args.n_secondary, args.seed)
+		sb = distributed.shard_bounds(args.n_secondary, world)
+		sec_slice = dict(secondary, ra=secondary['ra'][sb[rank]:sb[rank + 1]], dec=secondary['dec'][sb[rank]:sb[rank + 1]])
+		engine = distributed.SecondarySplitMatch(primary, [sec_slice], args.radius, args.completeness, device)
 	else:
-		engine = None
+		primary, secondary = make_workload(args.n_primary, args.n_secondary, args.seed)
 
 	if engine is None:
 		log = nway_amd.NullOutputLogger()
@@ -147,8 +229,22 @@ def main():
 		dens, dens_plus = nway_amd._compute_source_densities(tables, log)
 		comp = nway_amd._completeness_vector(args.completeness, 2)
 		params = _hip.make_params(2, scheme, args.radius, err, dens, dens_plus, nway_amd._prior_table(dens, dens_plus, comp))
+		torch.cuda.synchronize(device)
+		t0 = time.perf_counter()
 		cats = [_hip.DeviceCatalogue(t['ra'], t['dec'], np.asarray(t['error'], dtype=float), device) for t in tables]
+		torch.cuda.synchronize(device)
+		h2d_s = time.perf_counter() - t0
+		h2d_bytes = sum(c.ra.numel() * 8 * (2 + (1 if c.sigma is not None else 0)) for c in cats)
 		sizes = [c.n for c in cats]
+		# further copies of the secondary catalogue at other addresses: a 160 MB stream that is read
+		# again and again would otherwise be served by the 256 MiB Infinity Cache
+		sec_copies = [cats[1]]
+		for _ in range(max(args.sec_buffers, 1) - 1):
+			cp = _hip.DeviceCatalogue.__new__(_hip.DeviceCatalogue)
+			cp.ra, cp.dec = cats[1].ra.clone(), cats[1].dec.clone()
+			cp.sigma = None if cats[1].sigma is None else cats[1].sigma.clone()
+			cp.sigma_const, cp.n = cats[1].sigma_const, cats[1].n
+			sec_copies.append(cp)
 		# settle capacities with one untimed run
 		cap_pairs, cap_rows = nway_amd._estimate_capacities(sizes, [SKY_AREA, SKY_AREA], args.radius, scheme, True)
 		plan, st = _hip.run_plan(sizes, params, cats, cap_pairs, cap_rows, device, lean=True)
@@ -162,13 +258,25 @@ def main():
 
 		def step():
 			i = counter[0] % len(plans)
+			these = [cats[0], sec_copies[counter[0] % len(sec_copies)]]
 			counter[0] += 1
 			if streams[i] is None:
-				plans[i].enqueue(cats)
+				plans[i].enqueue(these)
 			else:
 				with torch.cuda.stream(streams[i]):
-					plans[i].enqueue(cats)
+					plans[i].enqueue(these)
 		read_status = plan.read_status
+		# device -> host download of the whole table, once, outside the timed region
+		torch.cuda.synchronize(device)
+		t0 = time.perf_counter()
+		d2h_bytes = 0
+		for name in ('sep_max', 'log_bf', 'dist_post', 'p_single', 'p_any', 'p_i', 'ncat', 'match_flag'):
+			d2h_bytes += plan.cols[name][:rows_per_step].cpu().numpy().nbytes
+		for col in plan.cols['idx'] + plan.cols['sep']:
+			d2h_bytes += col[:rows_per_step].cpu().numpy().nbytes
+		d2h_s = time.perf_counter() - t0
+		io = dict(h2d_ms=h2d_s * 1e3, h2d_bytes=int(h2d_bytes), d2h_ms=d2h_s * 1e3, d2h_bytes=int(d2h_bytes),
+			note='host arrays -> HBM before the timed region, table -> host after it; never part of `value`')
 	else:
 		step = engine.step
 		read_status = engine.read_status
@@ -187,7 +295,7 @@ def main():
 		step()
 	mask = (1 << _hip.STAGES) - 1 if args.profile_stages else (1 << 1)
 	for pl in plans:
-		pl.profile(mask)
+		pl.profile(mask, 1 if args.profile_stages else max(args.event_every, 1))
 	barrier()
 	t0 = time.perf_counter()
 	for _ in range(args.steps):
@@ -218,34 +326,54 @@ def main():
 		sweep_ms = ms[1] / max(launches[1], 1)
 		alg_bytes = 16.0 * n_sec_swept
 		achieved = alg_bytes / (sweep_ms * 1e-3) / 1e9 if sweep_ms > 0 else 0.0
-		traffic = None
+		traffic, traffic_source = None, None
 		tf = os.path.join(ROOT, 'profiles', 'sweep_traffic.json')
 		if os.path.exists(tf):
 			try:
 				rec = json.load(open(tf))
 				if rec.get('n_secondary') == n_sec_swept:
 					traffic = rec.get('hbm_bytes_per_launch')
+					traffic_source = ('NOT measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same command, '
+						'recorded in profiles/sweep_traffic.json (%s)' % rec.get('round', 'earlier round'))
 			except Exception:
 				traffic = None
+		# the whole pass, SURVEY 8(d): rank 0's pass (its primaries, the secondaries it streams, its rows)
+		local_rows = int(st[_hip.ST_ROWS])
+		if engine is None:
+			p_bytes = pass_bytes([primary, secondary], local_rows)
+		else:
+			p_bytes = engine.pass_bytes(local_rows)
+		if strong:
+			workload = ('C3-S synthetic 2-way, ONE job: %d primaries x %d secondaries over %d GPUs (every rank sweeps its 1/%d slice of the '
+				'secondaries against all the primaries; candidates routed to the owners of the primaries)' % (args.n_primary, args.n_secondary, world, world))
+		else:
+			workload = ('C3-S synthetic 2-way: %d primaries per GPU (%d in total) x %d secondaries (whole catalogue resident on every GPU)'
+				% (args.n_primary, args.n_primary * world, n_sec_swept))
+		workload += ', uniform sky, radius %g arcsec, completeness %g, seed %d' % (args.radius, args.completeness, args.seed)
 		out = dict(metric='candidate Bayes-factor evals/s', value=rows_per_step / (ms_per_step * 1e-3), unit='candidate evaluations/s',
-			n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=ms_per_step, higher_is_better=True, scaling='weak',
-			vs_baseline=None, dtype='f64', data='synthetic',
-			config=dict(workload='C3-S synthetic 2-way: %d primaries per GPU (%d in total) x %d secondaries (whole catalogue resident on every GPU), '
-				'uniform sky, radius %g arcsec, completeness %g, seed %d'
-				% (args.n_primary, args.n_primary * world, n_sec_swept, args.radius, args.completeness, args.seed),
+			n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=ms_per_step, higher_is_better=True,
+			scaling=('strong' if strong else 'weak'), vs_baseline=None, dtype='f64', data='synthetic',
+			config=dict(workload=workload,
 				rows_per_step=rows_per_step, distance_tests_per_step_rank0=int(st[_hip.ST_TESTS]),
 				survivors_per_step_rank0=int(st[_hip.ST_SURVIVORS]), registrations_rank0=int(st[_hip.ST_REGISTRATIONS]),
-				parallelism='primary-row shards x%d' % world, streams=len(plans),
-				setup_allgatherv=(None if engine is None else dict(seconds=engine.setup_seconds, bytes=engine.gathered_bytes,
-					note='one-time all-gatherv of the secondary columns (RCCL), outside the timed steps'))),
+				parallelism=('secondary-stream slices x%d + candidate routing' % world) if strong else ('primary-row shards x%d' % world),
+				streams=len(plans), secondary_buffers=(len(sec_copies) if engine is None else 1),
+				setup_exchange=(None if engine is None else dict(seconds=engine.setup_seconds, bytes=engine.gathered_bytes,
+					note='one-time exchange at set-up (RCCL), outside the timed steps'))),
 			roofline=dict(bound='hbm', kernel='k_sweep', achieved=achieved, peak=HBM_PEAK_GBS, unit='GB/s',
-				frac=achieved / HBM_PEAK_GBS, traffic=traffic, algorithmic_bytes_per_launch=alg_bytes,
-				launch_ms=sweep_ms, launches_timed=int(launches[1])))
+				frac=achieved / HBM_PEAK_GBS, traffic=traffic, traffic_source=traffic_source, algorithmic_bytes_per_launch=alg_bytes,
+				launch_ms=sweep_ms, launches_timed=int(launches[1]),
+				pass_bytes=p_bytes, pass_achieved=p_bytes / (ms_per_step * 1e-3) / 1e9, pass_frac=p_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+				pass_note='SURVEY 8(d): every input column once + 66 B per row, divided by the WHOLE step (all launches and the gaps between them); rank 0'))
+		if io is not None:
+			out['io'] = io
 		if args.profile_stages:
 			out['stages_ms'] = dict((name, ms[i] / max(launches[i], 1) * (launches[i] / float(args.steps)))
 				for i, name in enumerate(_hip.STAGE_NAMES))
 		if world == 1 and args.cpu_sample > 0:
-			out['cpu_baseline'], _ = cpu_baseline(primary, secondary, args.radius, args.completeness, args.cpu_sample)
+			out['cpu_baseline'], cpu_table = cpu_baseline(primary, secondary, args.radius, args.completeness, args.cpu_sample)
+			out['check'] = table_check(plan, [primary['name'], secondary['name']], cpu_table)
+			assert out['check']['ok'], 'the timed table differs from the CPU table: %r' % (out['check'],)
 		else:
 			out['cpu_baseline'] = None
 		print(json.dumps(out))

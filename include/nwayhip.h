@@ -188,6 +188,9 @@ int nwayhip_match_enqueue(nwayhip_plan* plan, const nwayhip_catalogue* h_cats, v
 #define NWAYHIP_PROFILE_RING 512
 int nwayhip_plan_profile(nwayhip_plan* plan, uint32_t stage_mask);
 int nwayhip_plan_profile_read(nwayhip_plan* plan, int64_t* h_launches /*[NWAYHIP_STAGES]*/, double* h_ms /*[NWAYHIP_STAGES]*/);
+/* An event pair on a dispatch costs the pipeline a few microseconds on this stack: with `every` > 1
+ * only every `every`-th launch of a single-launch stage (the sweep) carries one.  Default 1. */
+int nwayhip_plan_profile_stride(nwayhip_plan* plan, int32_t every);
 
 /* Per-primary group statistics (__init__.py:399-461 == nway.py:527-586) on a table whose
  * total = log_bf + sum(biases) was assembled by the caller (magnitude priors).

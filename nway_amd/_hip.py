@@ -72,6 +72,7 @@ SYMBOLS = {
 	'nwayhip_match_enqueue': (ctypes.c_int, [_vp, ctypes.POINTER(Catalogue), _vp, ctypes.c_size_t, ctypes.POINTER(Table), _vp, _vp]),
 	'nwayhip_plan_profile': (ctypes.c_int, [_vp, ctypes.c_uint32]),
 	'nwayhip_plan_profile_read': (ctypes.c_int, [_vp, ctypes.POINTER(_i64), ctypes.POINTER(_dbl)]),
+	'nwayhip_plan_profile_stride': (ctypes.c_int, [_vp, _i32]),
 	'nwayhip_group_stats': (ctypes.c_int, [_i64, _i64, _vp, _vp, _vp, _dbl, _vp, _vp, _vp, _vp, _vp]),
 	'nwayhip_bias_lookup': (ctypes.c_int, [_i64, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp]),
 	'nwayhip_catalogue_extent': (ctypes.c_int, [_vp, _vp, _i64, _vp, _vp]),
@@ -267,8 +268,10 @@ class MatchPlan(object):
 		check(self.lib.nwayhip_match_enqueue(self.handle, cats, ctypes.c_void_p(self.ws_ptr), self.ws_len,
 			ctypes.byref(self.table_struct), ptr(self.status), s))
 
-	def profile(self, stage_mask):
-		"""bracket the stages in ``stage_mask`` with HIP events on the pipeline's stream"""
+	def profile(self, stage_mask, every=1):
+		"""bracket the stages in ``stage_mask`` with HIP events on the pipeline's stream; ``every``:
+		only every n-th launch of a single-launch stage carries its event pair"""
+		check(self.lib.nwayhip_plan_profile_stride(self.handle, every))
 		check(self.lib.nwayhip_plan_profile(self.handle, stage_mask))
 
 	def profile_read(self):

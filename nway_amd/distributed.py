@@ -188,6 +188,16 @@ class ShardedMatch(object):
 	def read_status(self):
 		return self.plan.read_status()
 
+	def pass_bytes(self, rows):
+		"""algorithmic bytes of this rank's pass: its primaries and every secondary catalogue
+		read once (ra, dec, the positional error where it is a column) + the output columns of its rows"""
+		k = 1 + len(self.full_secondaries)
+		b = len(self.primary['ra']) * (16.0 + (8.0 if numpy.ndim(self.primary['error']) > 0 else 0.0))
+		for f in self.full_secondaries:
+			b += int(f['ra'].shape[0]) * (16.0 + (0.0 if numpy.ndim(f['error']) == 0 and not hasattr(f['error'], 'shape') else 8.0))
+		per_row = 4 * k + 8 * (k * (k - 1) // 2) + 8 + 1 + 8 * 5 + 1
+		return b + per_row * rows
+
 	def local_rows(self):
 		if self.compute is not None:
 			return len(self.table['ncat'])
