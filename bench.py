@@ -216,8 +216,10 @@ def main():
 		from nway_amd import distributed
 		primary, secondary = make_workload(args.n_primary, args.n_secondary, args.seed)
 		sb = distributed.shard_bounds(args.n_secondary, world)
+		pb = distributed.shard_bounds(args.n_primary, world)
 		sec_slice = dict(secondary, ra=secondary['ra'][sb[rank]:sb[rank + 1]], dec=secondary['dec'][sb[rank]:sb[rank + 1]])
-		engine = distributed.SecondarySplitMatch(primary, [sec_slice], args.radius, args.completeness, device)
+		prim_shard = dict(primary, ra=primary['ra'][pb[rank]:pb[rank + 1]], dec=primary['dec'][pb[rank]:pb[rank + 1]], error=primary['error'][pb[rank]:pb[rank + 1]])
+		engine = distributed.SecondarySplitMatch(prim_shard, [sec_slice], args.radius, args.completeness, device)
 	else:
 		primary, secondary = make_workload(args.n_primary, args.n_secondary, args.seed)
 

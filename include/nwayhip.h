@@ -171,6 +171,37 @@ int32_t nwayhip_plan_link_slots(const nwayhip_plan* plan);
 int nwayhip_match_enqueue(nwayhip_plan* plan, const nwayhip_catalogue* h_cats, void* workspace,
 	size_t workspace_bytes, const nwayhip_table* h_table, int64_t* d_status, void* stream);
 
+/* ---- secondary-split mode: several GPUs on ONE job ---------------------------------------
+ * (second half; the reference is a single process.)  Every rank registers ALL
+ * primaries and sweeps its own slice of every secondary catalogue; a candidate (primary,
+ * secondary) is exported to the rank that owns the primary; one all-to-all of the export buffers
+ * (the caller's: torch.distributed / RCCL, nway_amd/distributed.py) delivers them; the back half
+ * turns what arrived into the links of the rank's own primaries and runs the fused tail on them.
+ * Sparse path only (nwayhip_plan_link_slots() > 0).  The plan is created with n[0] = ALL primaries
+ * and n[c] = the rank's slice sizes; capacities and the table are for the rank's own rows.
+ *
+ * Export buffer: [destination rank][catalogue c - 1][1 + capacity] records of 32 bytes
+ * {int32 primary, int32 secondary (global indices), double ra, dec, sigma}; record 0 of a block
+ * is its header (`primary` = number of records).  Headers must be zero before the first front
+ * half; the back half resets them.  More records than `capacity` for one peer: the receiver
+ * raises NWAYHIP_FLAG_PAIR_OVERFLOW (come back with a larger capacity). */
+typedef struct nwayhip_split {
+	int32_t world, rank;
+	const int64_t* d_bounds;             /* device int64[world + 1]: rank r owns primaries [bounds[r], bounds[r+1]) */
+	int64_t h_p_lo, h_p_hi;              /* = bounds[rank], bounds[rank + 1] */
+	int64_t slice_offset[NWAYHIP_MAXCAT];/* [c >= 1]: global index of the first row of this rank's slice of catalogue c */
+	int64_t capacity;                    /* records per (peer, catalogue) block */
+	void* d_export;                      /* nwayhip_split_buffer_bytes() */
+	const void* d_import;                /* what the all-to-all delivered (same layout, [source rank] first) */
+} nwayhip_split;
+size_t nwayhip_split_buffer_bytes(const nwayhip_plan* plan, int32_t world, int64_t capacity);
+/* register (all primaries) + sweep (own slices) -> export buffer */
+int nwayhip_split_front_enqueue(nwayhip_plan* plan, const nwayhip_catalogue* h_cats, void* workspace, size_t workspace_bytes,
+	const nwayhip_split* h_split, int64_t* d_status, void* stream);
+/* import buffer -> links of the own primaries -> fused tail -> table (rows of the own primaries, global indices) */
+int nwayhip_split_back_enqueue(nwayhip_plan* plan, const nwayhip_catalogue* h_cats, void* workspace, size_t workspace_bytes,
+	const nwayhip_split* h_split, const nwayhip_table* h_table, int64_t* d_status, void* stream);
+
 /* Stage timing with HIP events recorded on the pipeline's own stream (bench.py's roofline leg).
  * stage_mask: bit s set => every launch group of stage s in subsequent nwayhip_match_enqueue
  * calls is bracketed by an event pair (ring of NWAYHIP_PROFILE_RING pairs per stage); the

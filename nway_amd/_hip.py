@@ -52,6 +52,13 @@ class Table(ctypes.Structure):
 		('match_flag', ctypes.c_void_p), ('group_start', ctypes.c_void_p)]
 
 
+class Split(ctypes.Structure):
+	"""nwayhip_split: secondary-split mode (several GPUs on one job)"""
+	_fields_ = [('world', ctypes.c_int32), ('rank', ctypes.c_int32), ('d_bounds', ctypes.c_void_p),
+		('h_p_lo', ctypes.c_int64), ('h_p_hi', ctypes.c_int64), ('slice_offset', ctypes.c_int64 * MAXCAT),
+		('capacity', ctypes.c_int64), ('d_export', ctypes.c_void_p), ('d_import', ctypes.c_void_p)]
+
+
 # every symbol include/nwayhip.h declares: (restype, argtypes)
 _vp, _i64, _i32, _dbl = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_double
 SYMBOLS = {
@@ -70,6 +77,9 @@ SYMBOLS = {
 	'nwayhip_plan_table_slots': (ctypes.c_int64, [_vp]),
 	'nwayhip_plan_link_slots': (ctypes.c_int32, [_vp]),
 	'nwayhip_match_enqueue': (ctypes.c_int, [_vp, ctypes.POINTER(Catalogue), _vp, ctypes.c_size_t, ctypes.POINTER(Table), _vp, _vp]),
+	'nwayhip_split_buffer_bytes': (ctypes.c_size_t, [_vp, _i32, _i64]),
+	'nwayhip_split_front_enqueue': (ctypes.c_int, [_vp, ctypes.POINTER(Catalogue), _vp, ctypes.c_size_t, ctypes.POINTER(Split), _vp, _vp]),
+	'nwayhip_split_back_enqueue': (ctypes.c_int, [_vp, ctypes.POINTER(Catalogue), _vp, ctypes.c_size_t, ctypes.POINTER(Split), ctypes.POINTER(Table), _vp, _vp]),
 	'nwayhip_plan_profile': (ctypes.c_int, [_vp, ctypes.c_uint32]),
 	'nwayhip_plan_profile_read': (ctypes.c_int, [_vp, ctypes.POINTER(_i64), ctypes.POINTER(_dbl)]),
 	'nwayhip_plan_profile_stride': (ctypes.c_int, [_vp, _i32]),
@@ -266,6 +276,23 @@ class MatchPlan(object):
 		cats = (Catalogue * self.ncat)(*[c.struct() for c in catalogues])
 		s = stream if stream is not None else current_stream_ptr(self.device)
 		check(self.lib.nwayhip_match_enqueue(self.handle, cats, ctypes.c_void_p(self.ws_ptr), self.ws_len,
+			ctypes.byref(self.table_struct), ptr(self.status), s))
+
+	def split_buffer_bytes(self, world, capacity):
+		return int(self.lib.nwayhip_split_buffer_bytes(self.handle, world, capacity))
+
+	def split_front(self, catalogues, split, stream=None):
+		"""secondary-split mode, first half: register all primaries, sweep the own slices, export the
+		candidates (``split``: a ``Split``); the caller's all-to-all comes next"""
+		cats = (Catalogue * self.ncat)(*[c.struct() for c in catalogues])
+		s = stream if stream is not None else current_stream_ptr(self.device)
+		check(self.lib.nwayhip_split_front_enqueue(self.handle, cats, ctypes.c_void_p(self.ws_ptr), self.ws_len, ctypes.byref(split), ptr(self.status), s))
+
+	def split_back(self, catalogues, split, stream=None):
+		"""second half: what the peers exported to this rank -> links of its own primaries -> table"""
+		cats = (Catalogue * self.ncat)(*[c.struct() for c in catalogues])
+		s = stream if stream is not None else current_stream_ptr(self.device)
+		check(self.lib.nwayhip_split_back_enqueue(self.handle, cats, ctypes.c_void_p(self.ws_ptr), self.ws_len, ctypes.byref(split),
 			ctypes.byref(self.table_struct), ptr(self.status), s))
 
 	def profile(self, stage_mask, every=1):

@@ -254,3 +254,283 @@ class ShardedMatch(object):
 				continue
 			out[key] = numpy.concatenate([numpy.asarray(g[key]) for g in gathered])
 		return out
+
+
+class SecondarySplitMatch(object):
+	"""ONE job over several GPUs (strong scaling; SURVEY.md 8(e), second half): the secondary STREAM
+	is split.  Every rank registers ALL primaries (their cell table is small), sweeps only its own
+	slice of every secondary catalogue, and exports each candidate (primary, secondary) to the rank
+	that owns the primary -- contiguous row ranges, so the rank-order concatenation of the tables is
+	the global table.  One all-to-all of fixed-size export buffers per step (RCCL over xGMI; a few
+	hundred KB per peer) is the only collective; the owner turns what arrives into links and runs the
+	fused tail on its own primaries.  Needs the sparse path (few chance neighbours per primary): dense
+	fields shard by primary rows alone (``ShardedMatch``), where every GPU has enough work per row.
+
+	primary: this rank's shard of the primary catalogue (the shards are all-gathered once at set-up)
+	secondaries: list of this rank's SLICES of the secondary catalogues (``error`` may be a scalar)
+	compute: None = the HIP pipeline (needs a GPU); the CPU tests pass ``(front, back)`` callables
+	  ``front(primary_all, slices, radius) -> per catalogue (p, s_local) candidate arrays`` and
+	  ``back(primary_own, received, radius, completeness, densities, scheme, prob_ratio_secondary)
+	  -> dict of columns`` to exercise the routing with gloo on CPU.
+	"""
+
+	def __init__(self, primary, secondaries, match_radius, prior_completeness, device, group=None,
+			prob_ratio_secondary=0.5, compute=None, capacity=None):
+		if isinstance(secondaries, dict):
+			secondaries = [secondaries]
+		self.primary = primary
+		self.secondary_slices = secondaries
+		self.match_radius = float(match_radius)
+		self.prior_completeness = prior_completeness
+		self.prob_ratio_secondary = prob_ratio_secondary
+		self.device = device
+		self.group = group
+		self.compute = compute
+		self.capacity = capacity
+		self.rank, self.world = world_info(group)
+		self.plan = None
+		self.setup()
+
+	# -- one-time exchange ---------------------------------------------------------------
+	def setup(self):
+		import torch
+		dist = _dist()
+		t0 = time.perf_counter()
+		dev = self.device if self.compute is None else torch.device('cpu')
+		f64 = lambda x: torch.as_tensor(numpy.ascontiguousarray(numpy.asarray(x, dtype=float))).to(dev)
+		# every rank needs ALL primaries: coordinates for the registration, errors for nothing but symmetry
+		ra, counts = allgatherv(f64(self.primary['ra']), self.group)
+		dec, _ = allgatherv(f64(self.primary['dec']), self.group)
+		err, _ = allgatherv(f64(numpy.broadcast_to(numpy.asarray(self.primary['error'], dtype=float), numpy.shape(self.primary['ra']))), self.group)
+		self.gathered_bytes = 24 * int(ra.shape[0])
+		self.primary_all = dict(name=self.primary['name'], ra=ra, dec=dec, error=err, area=self.primary['area'])
+		self.bounds = numpy.concatenate([[0], numpy.cumsum(counts)]).astype(numpy.int64)
+		self.primary_sizes = [int(c) for c in counts]
+		self.primary_offset = int(self.bounds[self.rank])
+		# global sizes and slice offsets of the secondaries
+		self.sec_global, self.sec_offset = [], []
+		for sl in self.secondary_slices:
+			n = torch.tensor([len(sl['ra'])], dtype=torch.int64, device=dev)
+			if self.world > 1:
+				sizes = [torch.zeros_like(n) for _ in range(self.world)]
+				dist.all_gather(sizes, n, group=self.group)
+				sizes = [int(x.item()) for x in sizes]
+			else:
+				sizes = [int(n.item())]
+			self.sec_global.append(sum(sizes))
+			self.sec_offset.append(sum(sizes[:self.rank]))
+		if self.compute is None:
+			torch.cuda.synchronize(self.device)
+		self.setup_seconds = time.perf_counter() - t0
+		self._decide()
+		if self.compute is None:
+			self._build_plan()
+
+	def _decide(self):
+		"""densities and cell scheme of the WHOLE catalogues (every rank must use the same)"""
+		import torch
+		import nway_amd
+		from nway_amd import _hip
+		log = nway_amd.NullOutputLogger()
+		names = [self.primary['name']] + [s['name'] for s in self.secondary_slices]
+		sizes = [int(self.bounds[-1])] + self.sec_global
+		areas = [self.primary['area']] + [s['area'] for s in self.secondary_slices]
+		self.dens, self.dens_plus = nway_amd._densities_from_sizes(names, sizes, areas, log)
+		err = self.match_radius / 60. / 60
+		local = [(numpy.asarray(self.primary['ra'], dtype=float), numpy.asarray(self.primary['dec'], dtype=float))]
+		local += [(numpy.asarray(s['ra'], dtype=float), numpy.asarray(s['dec'], dtype=float)) for s in self.secondary_slices]
+		scheme = nway_amd.choose_scheme([t for t in local if len(t[0]) > 0], err) if any(len(t[0]) for t in local) else _hip.SCHEME_FLAT
+		if self.world > 1:
+			dev = self.device if self.compute is None else torch.device('cpu')
+			s = torch.tensor([scheme], dtype=torch.int64, device=dev)
+			_dist().all_reduce(s, op=_dist().ReduceOp.MAX, group=self.group)  # the all-sky scheme wins
+			scheme = int(s.item())
+		self.scheme = scheme
+		self.global_sizes = sizes
+
+	def _build_plan(self):
+		import ctypes
+		import torch
+		import nway_amd
+		from nway_amd import _hip
+		k = 1 + len(self.secondary_slices)
+		err = self.match_radius / 60. / 60
+		comp = nway_amd._completeness_vector(self.prior_completeness, k)
+		self.params = _hip.make_params(k, self.scheme, self.match_radius, err, self.dens, self.dens_plus,
+			nway_amd._prior_table(self.dens, self.dens_plus, comp), prob_ratio_secondary=self.prob_ratio_secondary)
+		pa = self.primary_all
+		self.cats = [_hip.DeviceCatalogue(pa['ra'], pa['dec'], pa['error'], self.device)]
+		for s in self.secondary_slices:
+			self.cats.append(_hip.DeviceCatalogue(s['ra'], s['dec'], numpy.asarray(s['error'], dtype=float), self.device))
+		sizes = [c.n for c in self.cats]
+		n_own = self.primary_sizes[self.rank]
+		areas = [self.primary['area'] * 1.0] + [s['area'] * 1.0 for s in self.secondary_slices]
+		_, cap_rows = nway_amd._estimate_capacities([max(n_own, 1)] + self.sec_global, areas, self.match_radius, self.scheme, True)
+		self.bounds_dev = torch.as_tensor(self.bounds).to(self.device)
+		capacity = self.capacity or max(1024, 4 * max(self.primary_sizes) // self.world + 1024)
+		for attempt in range(6):
+			self.plan = _hip.MatchPlan(sizes, self.params, 65536, cap_rows, self.device, lean=True)
+			if not self.plan.sparse:
+				self.plan.close()
+				raise _hip.NwayHipError('the secondary-split mode needs the sparse path (few chance neighbours per primary); '
+					'shard dense fields by primary rows (ShardedMatch)')
+			nbytes = self.plan.split_buffer_bytes(self.world, capacity)
+			self.export = torch.zeros(nbytes, dtype=torch.uint8, device=self.device)
+			self.imported = torch.zeros(nbytes, dtype=torch.uint8, device=self.device)
+			sp = _hip.Split()
+			sp.world, sp.rank = self.world, self.rank
+			sp.d_bounds = self.bounds_dev.data_ptr()
+			sp.h_p_lo, sp.h_p_hi = int(self.bounds[self.rank]), int(self.bounds[self.rank + 1])
+			for c, off in enumerate(self.sec_offset):
+				sp.slice_offset[c + 1] = off
+			sp.capacity = capacity
+			sp.d_export = self.export.data_ptr()
+			sp.d_import = self.imported.data_ptr()
+			self.split = sp
+			self.capacity = capacity
+			self.step()
+			st = self.plan.read_status()
+			flags = int(st[_hip.ST_FLAGS])
+			# every rank must take the same decision: the capacities are part of the exchange's layout
+			f = torch.tensor([flags, int(st[_hip.ST_ROWS])], dtype=torch.int64, device=self.device)
+			if self.world > 1:
+				allf = [torch.zeros_like(f) for _ in range(self.world)]
+				_dist().all_gather(allf, f, group=self.group)
+				flags_any = 0
+				for x in allf:
+					flags_any |= int(x[0].item())
+			else:
+				flags_any = flags
+			if flags_any == 0:
+				self.status = st
+				return
+			self.plan.close()
+			if flags_any & _hip.FLAG_PAIR_OVERFLOW:
+				capacity *= 4
+			if flags_any & _hip.FLAG_ROW_OVERFLOW:
+				cap_rows = min(cap_rows * 2, (1 << 31) - 4096)
+			if flags_any & (_hip.FLAG_SLOT_OVERFLOW | _hip.FLAG_LOOKBACK | _hip.FLAG_REG_OVERFLOW):
+				raise _hip.NwayHipError('the secondary-split mode does not fit this input (status flags %d): shard by primary rows' % flags_any)
+		raise _hip.NwayHipError('secondary-split mode: capacities could not be settled')
+
+	# -- per step ------------------------------------------------------------------------
+	def _exchange(self):
+		dist = _dist()
+		if self.world == 1:
+			self.imported.copy_(self.export)
+		elif dist.get_backend(self.group) == 'nccl':
+			dist.all_to_all_single(self.imported, self.export, group=self.group)
+		else:
+			# gloo (functional tests, several ranks sharing one GPU): through host memory
+			src = self.export.cpu()
+			dst = src.clone()
+			dist.all_to_all_single(dst, src, group=self.group)
+			self.imported.copy_(dst)
+
+	def step(self):
+		"""one pass: register + sweep of the own slices, ONE all-to-all, import + fused tail"""
+		if self.compute is not None:
+			return self._step_cpu()
+		self.plan.split_front(self.cats, self.split)
+		self._exchange()
+		self.plan.split_back(self.cats, self.split)
+
+	def _step_cpu(self):
+		import torch
+		dist = _dist()
+		front, back = self.compute
+		host = lambda t: t.numpy() if hasattr(t, 'numpy') else numpy.asarray(t)
+		pa = dict(self.primary_all, ra=host(self.primary_all['ra']), dec=host(self.primary_all['dec']), error=host(self.primary_all['error']))
+		cands = front(pa, self.secondary_slices, self.match_radius, self.scheme)
+		received = []
+		for c, (p, s_local) in enumerate(cands):
+			sl = self.secondary_slices[c]
+			p = numpy.asarray(p, dtype=numpy.int64)
+			s_local = numpy.asarray(s_local, dtype=numpy.int64)
+			owner = numpy.searchsorted(self.bounds, p, side='right') - 1
+			order = numpy.argsort(owner, kind='stable')
+			rec = numpy.stack([p[order].astype(float), (s_local[order] + self.sec_offset[c]).astype(float), numpy.asarray(sl['ra'], dtype=float)[s_local[order]],
+				numpy.asarray(sl['dec'], dtype=float)[s_local[order]],
+				numpy.broadcast_to(numpy.asarray(sl['error'], dtype=float), numpy.shape(sl['ra']))[s_local[order]]], axis=1) if len(p) else numpy.zeros((0, 5))
+			send_counts = numpy.bincount(owner, minlength=self.world).astype(numpy.int64)
+			if self.world > 1:
+				sc = torch.as_tensor(send_counts)
+				rc = torch.zeros_like(sc)
+				dist.all_to_all_single(rc, sc, group=self.group)
+				out = torch.zeros((int(rc.sum().item()), 5), dtype=torch.float64)
+				dist.all_to_all_single(out, torch.as_tensor(numpy.ascontiguousarray(rec)), [int(x) for x in rc], [int(x) for x in send_counts], group=self.group)
+				got = out.numpy()
+			else:
+				got = rec
+			received.append(got)
+		lo, hi = int(self.bounds[self.rank]), int(self.bounds[self.rank + 1])
+		own = dict(self.primary, ra=numpy.asarray(self.primary['ra'], dtype=float), dec=numpy.asarray(self.primary['dec'], dtype=float))
+		self.table = back(own, lo, received, [s['name'] for s in self.secondary_slices], [s['area'] for s in self.secondary_slices],
+			self.match_radius, self.prior_completeness, (self.dens, self.dens_plus), self.scheme, self.prob_ratio_secondary)
+		return self.table
+
+	def read_status(self):
+		return self.plan.read_status()
+
+	def local_rows(self):
+		if self.compute is not None:
+			return len(self.table['ncat'])
+		from nway_amd import _hip
+		return int(self.plan.read_status()[_hip.ST_ROWS])
+
+	def total_rows(self):
+		import torch
+		n = self.local_rows()
+		if self.world == 1:
+			return n
+		dev = self.device if self.compute is None else torch.device('cpu')
+		t = torch.tensor([n], dtype=torch.int64, device=dev)
+		_dist().all_reduce(t, group=self.group)
+		return int(t.item())
+
+	def pass_bytes(self, rows):
+		"""algorithmic bytes of this rank's pass: all the primaries it registers, its slices
+		of the secondaries (ra, dec; the error where it is a column) + the output columns of its rows"""
+		k = 1 + len(self.secondary_slices)
+		b = int(self.bounds[-1]) * 16.0 + self.primary_sizes[self.rank] * 8.0
+		for s in self.secondary_slices:
+			b += len(s['ra']) * (16.0 + (8.0 if numpy.ndim(s['error']) > 0 else 0.0))
+		per_row = 4 * k + 8 * (k * (k - 1) // 2) + 8 + 1 + 8 * 5 + 1
+		return b + per_row * rows
+
+	def local_table(self):
+		"""this rank's block of the global table as host columns (global indices throughout)"""
+		if self.compute is not None:
+			return dict(self.table)
+		from nway_amd import _hip
+		st = self.plan.read_status()
+		m = int(st[_hip.ST_ROWS])
+		names = [self.primary['name']] + [s['name'] for s in self.secondary_slices]
+		t = {}
+		for c, nme in enumerate(names):
+			t[nme] = self.plan.cols['idx'][c][:m].cpu().numpy().astype(numpy.int64)
+		for p, (i, j) in enumerate(_hip.pair_columns(len(names))):
+			t['Separation_%s_%s' % (names[i], names[j])] = self.plan.cols['sep'][p][:m].cpu().numpy()
+		for src, dst in (('sep_max', 'Separation_max'), ('log_bf', 'dist_bayesfactor_uncorrected'), ('log_bf_corrected', 'dist_bayesfactor'),
+				('dist_post', 'dist_post'), ('p_single', 'p_single'), ('p_any', 'prob_has_match'), ('p_i', 'prob_this_match')):
+			t[dst] = self.plan.cols[src][:m].cpu().numpy()
+		t['ncat'] = self.plan.cols['ncat'][:m].cpu().numpy().astype(numpy.int64)
+		t['match_flag'] = self.plan.cols['match_flag'][:m].cpu().numpy().astype(numpy.int64)
+		return t
+
+	def gather_table(self, dst=0):
+		"""global table on rank ``dst`` (rank-order concatenation); None elsewhere"""
+		dist = _dist()
+		local = self.local_table()
+		if self.world == 1:
+			return local
+		gathered = [None] * self.world if self.rank == dst else None
+		dist.gather_object(local, gathered, dst=dst, group=self.group)
+		if self.rank != dst:
+			return None
+		out = {}
+		for key in gathered[0]:
+			if key.startswith('_'):
+				continue
+			out[key] = numpy.concatenate([numpy.asarray(g[key]) for g in gathered])
+		return out

@@ -91,3 +91,78 @@ def test_shard_bounds():
 	b = distributed.shard_bounds(10, 4)
 	assert list(b) == [0, 3, 6, 8, 10]
 	assert list(distributed.shard_bounds(2, 4)) == [0, 1, 2, 2, 2]
+
+
+# ---- secondary-split mode (one job over several ranks): CPU stand-ins for the two device halves ----
+
+def split_front(primary_all, slices, radius, scheme):
+	"""what the device front half exports: per catalogue the candidates (primary, secondary of the slice)"""
+	import nway_oracle as orc
+	out = []
+	for sl in slices:
+		tup = orc.enumerate_tuples([(primary_all['ra'], primary_all['dec']), (sl['ra'], sl['dec'])], radius / 3600., scheme, radius)
+		tup = tup[tup[:, 1] >= 0]
+		out.append((tup[:, 0], tup[:, 1]))
+	return out
+
+
+def split_back(own, p_lo, received, names, areas, radius, completeness, densities, scheme, ratio):
+	"""what the device back half does with the records it received: the match of the own primaries
+	against exactly those secondaries, with the densities and the scheme of the whole catalogues"""
+	import nway_oracle as orc
+	tables = [dict(name=own['name'], ra=own['ra'], dec=own['dec'], error=np.broadcast_to(np.asarray(own['error'], dtype=float), np.shape(own['ra'])), area=own['area'])]
+	gidx = []
+	for c, rec in enumerate(received):
+		g, first = np.unique(rec[:, 1].astype(np.int64), return_index=True)  # ascending global index: the order of the rows is kept
+		gidx.append(g)
+		tables.append(dict(name=names[c], ra=rec[first, 2], dec=rec[first, 3], error=rec[first, 4], area=areas[c]))
+	t = orc.nway_match(tables, radius, completeness, prob_ratio_secondary=ratio, densities=densities, scheme=scheme)
+	t[own['name']] = t[own['name']] + p_lo
+	for c, g in enumerate(gidx):
+		col = t[names[c]]
+		t[names[c]] = np.where(col >= 0, g[np.maximum(col, 0)] if len(g) else col, -1)
+	return t
+
+
+def split_worker(rank, world, port, outfile, k):
+	os.environ['MASTER_ADDR'] = '127.0.0.1'
+	os.environ['MASTER_PORT'] = str(port)
+	dist.init_process_group('gloo', rank=rank, world_size=world)
+	try:
+		from nway_amd import distributed
+		A, B, C = make_catalogues()
+		pb = [0, 150, len(A['ra'])]       # uneven shards of the primaries
+		bb = [0, 3500, len(B['ra'])]      # and of the secondary streams
+		cb = [0, 1200, len(C['ra'])]
+		def rows(t, lo, hi):
+			return dict(t, ra=t['ra'][lo:hi], dec=t['dec'][lo:hi], error=t['error'][lo:hi])
+		secs = [rows(B, bb[rank], bb[rank + 1]), rows(C, cb[rank], cb[rank + 1])][:k - 1]
+		sm = distributed.SecondarySplitMatch(rows(A, pb[rank], pb[rank + 1]), secs, 20., 0.85, device=torch.device('cpu'),
+			compute=(split_front, split_back))
+		assert list(sm.bounds) == pb and sm.primary_offset == pb[rank]
+		assert sm.sec_global == [len(B['ra']), len(C['ra'])][:k - 1] and sm.sec_offset == [bb[rank], cb[rank]][:k - 1]
+		sm.step()
+		total = sm.total_rows()
+		table = sm.gather_table(dst=0)
+		if rank == 0:
+			np.savez(outfile, total=total, **table)
+	finally:
+		dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('k', [2, 3])
+def test_secondary_split_equals_unsharded(tmp_path, k):
+	"""every rank sweeps only its slice of the secondaries against ALL primaries; the candidates are
+	routed to the owners of the primaries (all-to-all-v with global indices, uneven slices); the
+	rank-order concatenation of the owners' tables is the unsharded table"""
+	import nway_oracle as orc
+	outfile = str(tmp_path / 'split.npz')
+	mp.spawn(split_worker, args=(2, free_port(), outfile, k), nprocs=2, join=True)
+	got = np.load(outfile)
+	A, B, C = make_catalogues()
+	want = orc.nway_match([A, B, C][:k], 20., 0.85)
+	assert int(got['total']) == len(want['ncat']) > 400
+	for key in want:
+		if key.startswith('_'):
+			continue
+		np.testing.assert_array_equal(got[key], want[key], err_msg=key)
