@@ -135,31 +135,62 @@ def read_table(filename, hdu=1):
 def _decode_table(raw, header):
 	nrows = header['NAXIS2']
 	width = header['NAXIS1']
-	fields = []
-	formats = []
+	fields = []     # every column, for the row layout
+	kept = []       # (field, tform, scale, zero) of the columns that are handed on
+	# bytes per element of the column types that are not decoded (bit, complex, descriptors): such a
+	# column is skipped with a warning instead of making the whole catalogue unreadable
+	other = {'X': None, 'C': 8, 'M': 16, 'P': 8, 'Q': 16}
 	for i in range(1, header['TFIELDS'] + 1):
 		name = header['TTYPE%d' % i]
 		tform = header['TFORM%d' % i].strip()
-		m = re.match(r'^(\d*)([LBIJKEDA])', tform)
+		m = re.match(r'^(\d*)([LBIJKEDAXCMPQ])', tform)
 		if not m:
 			raise FitsError('unsupported TFORM "%s" for column "%s"' % (tform, name))
 		rep = int(m.group(1)) if m.group(1) else 1
 		letter = m.group(2)
-		formats.append(tform)
+		if letter in other:
+			nbytes = (rep + 7) // 8 if letter == 'X' else rep * other[letter]
+			if letter in 'PQ':
+				nbytes = other[letter] * (1 if m.group(1) == '' else min(rep, 1))
+			fields.append(('_skip%d' % i, 'V%d' % nbytes))
+			import warnings
+			warnings.warn('column "%s" (TFORM %s) is not read' % (name, tform))
+			continue
 		if letter == 'A':
-			fields.append((name, 'S%d' % rep))
+			fld = (name, 'S%d' % rep)
 		elif rep == 1:
-			fields.append((name, _TFORM[letter][0]))
+			fld = (name, _TFORM[letter][0])
 		else:
-			fields.append((name, _TFORM[letter][0], (rep,)))
+			fld = (name, _TFORM[letter][0], (rep,))
+		fields.append(fld)
+		kept.append((fld, tform, header.get('TSCAL%d' % i, 1), header.get('TZERO%d' % i, 0)))
 	be = numpy.dtype(fields)
 	if be.itemsize != width:
 		raise FitsError('row width mismatch: header says %d, columns give %d' % (width, be.itemsize))
 	table = numpy.frombuffer(raw, dtype=be, count=nrows)
-	native = numpy.dtype([(d[0],) + ((numpy.dtype(d[1]).newbyteorder('='),) + tuple(d[2:])) for d in fields])
-	out = numpy.empty(nrows, dtype=native)
-	for d in fields:
-		out[d[0]] = table[d[0]]
+	native = []
+	for fld, tform, scale, zero in kept:
+		base = numpy.dtype(fld[1]).newbyteorder('=')
+		if (scale != 1 or zero != 0) and base.kind in 'iu':
+			# scaled integers: unsigned columns are stored with TZERO = 2^(bits - 1) (the FITS convention,
+			# what astropy writes for IDs); anything else becomes float64 like astropy's
+			unsigned = scale == 1 and zero == 2 ** (8 * base.itemsize - 1)
+			base = numpy.dtype('u%d' % base.itemsize) if unsigned else numpy.dtype('f8')
+		native.append((fld[0], base) + tuple(fld[2:]))
+	out = numpy.empty(nrows, dtype=numpy.dtype(native))
+	formats = []
+	for (fld, tform, scale, zero), nat in zip(kept, native):
+		col = table[fld[0]]
+		if numpy.dtype(nat[1]).kind == 'u' and numpy.dtype(fld[1]).kind == 'i':
+			if numpy.dtype(nat[1]).itemsize == 8:
+				out[fld[0]] = col.astype(numpy.int64).view(numpy.uint64) ^ numpy.uint64(1 << 63)  # + 2^63 mod 2^64
+			else:
+				out[fld[0]] = (col.astype(numpy.int64) + int(zero)).astype(nat[1])
+		elif scale != 1 or zero != 0:
+			out[fld[0]] = col * scale + zero
+		else:
+			out[fld[0]] = col
+		formats.append(tform if numpy.dtype(nat[1]).kind != 'f' or numpy.dtype(fld[1]).kind == 'f' else re.sub(r'[BIJK]', 'D', tform))
 	return Table(out, header, formats)
 
 
@@ -210,14 +241,20 @@ def write_table(filename, columns, extname, primary_header=None, table_header=No
 		raise FitsError('"%s" exists' % filename)
 	nrows = len(columns[0][2]) if columns else 0
 	fields = []
+	tzero = {}
 	for name, tform, arr in columns:
 		m = re.match(r'^(\d*)([LBIJKEDA])', tform)
 		rep = int(m.group(1)) if m.group(1) else 1
 		letter = m.group(2)
 		if letter == 'A':
 			fields.append((name, 'S%d' % rep))
-		else:
+		elif rep == 1:
 			fields.append((name, _TFORM[letter][0]))
+		else:
+			fields.append((name, _TFORM[letter][0], (rep,)))  # a vector column keeps its repeat count
+		a = numpy.asarray(arr)
+		if a.dtype.kind == 'u' and letter in 'IJK' and a.dtype.itemsize == numpy.dtype(_TFORM[letter][0]).itemsize:
+			tzero[name] = 2 ** (8 * a.dtype.itemsize - 1)  # the FITS convention for unsigned integers
 	be = numpy.dtype(fields)
 	data = numpy.zeros(nrows, dtype=be)
 	for (name, tform, arr), fld in zip(columns, fields):
@@ -226,8 +263,10 @@ def write_table(filename, columns, extname, primary_header=None, table_header=No
 			raise FitsError('column "%s" has %d rows, expected %d' % (name, len(arr), nrows))
 		if fld[1].startswith('S') and arr.dtype.kind == 'U':
 			arr = numpy.char.encode(arr, 'ascii')
+		if name in tzero:
+			arr = (arr.astype(numpy.int64) - tzero[name]) if arr.dtype.itemsize < 8 else (arr ^ numpy.uint64(1 << 63)).view(numpy.int64)
 		with numpy.errstate(invalid='ignore', over='ignore'):
-			data[name] = arr.astype(be[name], copy=False)
+			data[name] = arr.astype(be[name].base if be[name].subdtype else be[name], copy=False)
 
 	now = datetime.datetime.now().replace(microsecond=0).isoformat()
 	pcards = [_card('SIMPLE', True, 'Standard FITS format'), _card('BITPIX', 8), _card('NAXIS', 0),
@@ -248,6 +287,8 @@ def write_table(filename, columns, extname, primary_header=None, table_header=No
 	for i, (name, tform, arr) in enumerate(columns, 1):
 		tcards.append(_card('TTYPE%d' % i, name))
 		tcards.append(_card('TFORM%d' % i, tform))
+		if name in tzero:
+			tcards.append(_card('TZERO%d' % i, tzero[name]))
 	for k, v in (table_header or {}).items():
 		tcards.append(_card(k, v))
 	raw = data.tobytes()

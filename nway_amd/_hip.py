@@ -348,49 +348,67 @@ def make_params(ncat, scheme, radius_arcsec, err_deg, dens, dens_plus, prior_tab
 	return p
 
 
+CAPACITY_LIMIT = (1 << 31) - 4096  # row / link positions are int32 on the device
+
+
 def run_plan(sizes, params, catalogues, cap_pairs, cap_rows, device, max_retries=6, lean=False):
-	"""enqueue, synchronise, grow the capacities on overflow; returns (plan, status)"""
-	for attempt in range(max_retries):
+	"""enqueue, synchronise, grow the capacities on overflow; returns (plan, status).
+
+	Every kind of overflow has its own budget of ``max_retries`` repeats (a clustered k >= 4 match
+	may need the general path, a larger link region AND several row doublings): the status words
+	report exact needs where a run could count them (links, the rows of a 2-way table), a lower
+	bound otherwise (an expansion level that overflowed ends the run: rows grow fourfold then)."""
+	tries = dict(table=0, path=0, pairs=0, rows=0)
+	while True:
 		plan = MatchPlan(sizes, params, cap_pairs, cap_rows, device, lean=lean)
 		plan.enqueue(catalogues)
 		st = plan.read_status()
 		flags = int(st[ST_FLAGS])
-		if flags & FLAG_REG_OVERFLOW and plan.sparse:
-			# the direct-mapped table of the sparse path has a fixed size and bounded displacement:
-			# primaries piled up in a few cells go to the general path
+		if flags == 0:
+			return plan, st
+		sparse = plan.sparse
+		slots = plan.table_slots()
+		plan.close()
+		del plan
+
+		def spend(kind):
+			tries[kind] += 1
+			if tries[kind] > max_retries:
+				raise NwayHipError('match table capacity could not be settled (%s, %d attempts; status flags %d)' % (kind, max_retries, flags))
+		if flags & (FLAG_SLOT_OVERFLOW | FLAG_LOOKBACK) or (flags & FLAG_REG_OVERFLOW and sparse):
+			# the sparse path does not fit this input (a primary with more candidates than slots,
+			# primaries piled up in a few cells): repeat on the general path
+			spend('path')
 			params.link_slots = -1
-			plan.close()
-			del plan
 			continue
 		if flags & FLAG_REG_OVERFLOW:
 			# the cell table is sized for the expected registrations per primary; catalogues piled
 			# up near a pole need more: come back with a larger table (bounded)
-			slots = plan.table_slots() * 4
-			plan.close()
-			del plan
+			spend('table')
+			slots *= 4
 			if slots > 256 * max(int(sizes[0]), 1) + (1 << 16):
 				raise NwayHipError('primary cell registration overflowed (sources piled up on a pole?)')
 			params.table_slots = slots
 			continue
-		if flags & (FLAG_SLOT_OVERFLOW | FLAG_LOOKBACK):
-			# the sparse 2-way fast path does not fit this input: repeat on the general path
-			params.link_slots = -1
-			plan.close()
-			del plan
-			continue
-		if flags & (FLAG_PAIR_OVERFLOW | FLAG_ROW_OVERFLOW):
+		if flags & FLAG_PAIR_OVERFLOW:
+			spend('pairs')
 			need_pairs = int(max(st[ST_PAIRS:ST_PAIRS + 8]))
 			cap_pairs = max(cap_pairs, int(need_pairs * 1.05) + 1024)
-			if flags & FLAG_PAIR_OVERFLOW and int(st[ST_REGION_NEED]) > 0:
+			if int(st[ST_REGION_NEED]) > 0:
 				# the total may fit, but one workgroup's region of the link arrays did not (clustered input)
 				params.link_region_min = max(int(params.link_region_min), int(int(st[ST_REGION_NEED]) * 1.3) + 64)
-			if flags & FLAG_ROW_OVERFLOW and not flags & FLAG_PAIR_OVERFLOW:
-				cap_rows = max(cap_rows * 2, int(st[ST_ROWS] * 1.05) + 1024)
-			elif flags & FLAG_ROW_OVERFLOW:
-				cap_rows = cap_rows * 2
-			plan.close()
-			del plan
-			torch().cuda.empty_cache()
-			continue
-		return plan, st
-	raise NwayHipError('match table capacity could not be settled after %d attempts' % max_retries)
+		if flags & FLAG_ROW_OVERFLOW:
+			spend('rows')
+			if cap_rows >= CAPACITY_LIMIT:
+				raise NwayHipError('the match table would have more than 2^31 rows: split the primary catalogue')
+			reported = int(st[ST_ROWS])
+			if flags & FLAG_PAIR_OVERFLOW:
+				cap_rows = cap_rows * 2             # the links were incomplete: the row count means little
+			elif params.ncat == 2:
+				cap_rows = int(reported * 1.02) + 1024  # exact: one repeat settles it
+			else:
+				cap_rows = max(cap_rows * 4, int(reported * 1.5) + 1024)  # a level overflowed: lower bound only
+			cap_rows = min(cap_rows, CAPACITY_LIMIT)
+		if cap_pairs > CAPACITY_LIMIT:
+			raise NwayHipError('more than 2^31 links: split the primary catalogue')
+		torch().cuda.empty_cache()

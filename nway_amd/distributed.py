@@ -139,9 +139,11 @@ class ShardedMatch(object):
 			e = f['error']
 			sec.append(dict(name=f['name'], ra=f['ra'], dec=f['dec'], error=e, area=f['area'], mags=[], maghists=[], magnames=[]))
 		prim = dict(self.primary)
-		# density of the WHOLE primary catalogue: scale the area of the shard
+		# density of the WHOLE primary catalogue: scale the area of the shard (the CPU stand-ins of the
+		# tests derive the densities from the tables they are given)
 		total = float(sum(self.primary_sizes))
-		prim['area'] = self.primary['area'] * (len(self.primary['ra']) / total) if total > 0 else self.primary['area']
+		if total > 0 and len(self.primary['ra']) > 0:
+			prim['area'] = self.primary['area'] * (len(self.primary['ra']) / total)
 		return [prim] + sec
 
 	def _build_plan(self):
@@ -149,6 +151,7 @@ class ShardedMatch(object):
 		from nway_amd import _hip
 		tables = self._tables()
 		log = nway_amd.NullOutputLogger()
+		self.empty = len(self.primary['ra']) == 0  # (a rank without primaries still takes part in every collective)
 		k = len(tables)
 		err = self.match_radius / 60. / 60
 		# the flat-vs-all-sky decision needs every catalogue's extent: primaries are sharded, so
@@ -162,8 +165,10 @@ class ShardedMatch(object):
 			_dist().all_reduce(s, op=_dist().ReduceOp.MAX, group=self.group)
 			scheme = int(s.item())
 		self.scheme = scheme
+		# densities of the WHOLE catalogues (the global primary count over the full area: the same nu_0
+		# on every rank, also on one whose shard is empty)
 		dens, dens_plus = nway_amd._densities_from_sizes([t['name'] for t in tables],
-			[len(self.primary['ra'])] + [int(t['ra'].shape[0]) for t in tables[1:]], [t['area'] for t in tables], log)
+			[int(sum(self.primary_sizes))] + [int(t['ra'].shape[0]) for t in tables[1:]], [self.primary['area']] + [t['area'] for t in tables[1:]], log)
 		comp = nway_amd._completeness_vector(self.prior_completeness, k)
 		self.params = _hip.make_params(k, scheme, self.match_radius, err, dens, dens_plus, nway_amd._prior_table(dens, dens_plus, comp),
 			prob_ratio_secondary=self.prob_ratio_secondary)
@@ -172,6 +177,9 @@ class ShardedMatch(object):
 			self.cats.append(_hip.DeviceCatalogue(t['ra'], t['dec'], t['error'], self.device))
 		sizes = [c.n for c in self.cats]
 		cap_pairs, cap_rows = nway_amd._estimate_capacities(sizes, [t['area'] * 1.0 for t in tables], self.match_radius, scheme, True)
+		if self.empty:
+			self.plan, self.status = None, numpy.zeros(_hip.STATUS_WORDS, dtype=numpy.int64)
+			return
 		self.plan, self.status = _hip.run_plan(sizes, self.params, self.cats, cap_pairs, cap_rows, self.device, lean=True)
 
 	# -- per batch -----------------------------------------------------------------------
@@ -183,10 +191,11 @@ class ShardedMatch(object):
 				error=(t['error'] if numpy.ndim(t['error']) == 0 else numpy.asarray(t['error']))) for t in tables]
 			self.table = self.compute(tables, self.match_radius, self.prior_completeness, prob_ratio_secondary=self.prob_ratio_secondary)
 			return self.table
-		self.plan.enqueue(self.cats)
+		if not self.empty:
+			self.plan.enqueue(self.cats)
 
 	def read_status(self):
-		return self.plan.read_status()
+		return self.status if self.plan is None else self.plan.read_status()
 
 	def pass_bytes(self, rows):
 		"""algorithmic bytes of this rank's pass: its primaries and every secondary catalogue
@@ -202,7 +211,7 @@ class ShardedMatch(object):
 		if self.compute is not None:
 			return len(self.table['ncat'])
 		from nway_amd import _hip
-		return int(self.plan.read_status()[_hip.ST_ROWS])
+		return int(self.read_status()[_hip.ST_ROWS])
 
 	def total_rows(self):
 		"""rows produced by all ranks in one step"""
@@ -219,6 +228,14 @@ class ShardedMatch(object):
 		"""this rank's block of the global table as host columns (global primary indices)"""
 		if self.compute is not None:
 			t = dict(self.table)
+		elif self.plan is None:
+			names = [self.primary['name']] + [f['name'] for f in self.full_secondaries]
+			from nway_amd import _hip
+			t = dict((nme, numpy.zeros(0, dtype=numpy.int64)) for nme in names + ['ncat', 'match_flag'])
+			for i, j in _hip.pair_columns(len(names)):
+				t['Separation_%s_%s' % (names[i], names[j])] = numpy.zeros(0)
+			for dst in ('Separation_max', 'dist_bayesfactor_uncorrected', 'dist_bayesfactor', 'dist_post', 'p_single', 'prob_has_match', 'prob_this_match'):
+				t[dst] = numpy.zeros(0)
 		else:
 			from nway_amd import _hip
 			st = self.plan.read_status()
