@@ -212,3 +212,37 @@ def test_elliptical_correction_against_row_by_row_oracle():
 	assert (want != base).sum() > 100
 	np.testing.assert_allclose(got, want, rtol=1e-9, atol=1e-9)
 	res.plan.close()
+
+
+@pytest.mark.gpu
+def test_offsets_known_answers():
+	"""nwayhip_offsets against answers worked out by hand from the rotation astropy documents for
+	SkyOffsetFrame (the origin goes to (0, 0), no roll: R = R_y(-dec_a) R_z(ra_a)), i.e. NOT taken
+	from oracle/elliptical_oracle.py.  For b seen from a: x' = cos(dec_a) cos(dec_b) cos(dra) +
+	sin(dec_a) sin(dec_b), y' = cos(dec_b) sin(dra), z' = -sin(dec_a) cos(dec_b) cos(dra) +
+	cos(dec_a) sin(dec_b); lon' = atan2(y', x'), lat' = asin(z'); dist3d returns (0 - lon', 0 - lat')
+	(fastskymatch.py:62-67)."""
+	from nway_amd import elliptical
+	cases = [
+		# a_ra, a_dec, b_ra, b_dec, d_lon, d_lat
+		(10.0, 20.0, 10.0, 21.0, 0.0, -1.0),      # same meridian: x' = cos 1, z' = sin 1
+		(30.0, 0.0, 31.5, 0.0, -1.5, 0.0),        # on the equator: lon' = 1.5
+		(0.0, 89.0, 180.0, 89.0, 0.0, -2.0),      # across the pole: x' = cos 2, z' = sin 2 -- straight north by 2 deg
+		(359.5, 0.0, 0.5, 0.0, -1.0, 0.0),        # across the RA seam
+		(0.5, 0.0, 359.5, 0.0, 1.0, 0.0),
+		(0.0, 0.0, 90.0, 45.0, -90.0, -45.0),     # x' = 0, y' = cos 45, z' = sin 45
+		(0.0, 90.0, 0.0, 89.0, 0.0, 1.0),         # from the pole: z' = -cos 89 -> lat' = -1
+		(200.0, -35.0, 200.0, -35.0, 0.0, 0.0),   # the same point
+		(120.0, 60.0, 300.0, -60.0, 180.0, 0.0),  # the antipode: x' = -1, y' = 0 -> lon' = 180 (either sign of 180 is the same angle)
+	]
+	a_ra, a_dec, b_ra, b_dec, want_lon, want_lat = [np.array(c) for c in zip(*cases)]
+	lon, lat = elliptical.offsets(a_ra, a_dec, b_ra, b_dec)
+	np.testing.assert_allclose(lat, want_lat, rtol=0, atol=1e-11)
+	dlon = (lon - want_lon + 180.0) % 360.0 - 180.0
+	np.testing.assert_allclose(dlon, 0.0, rtol=0, atol=1e-11)
+	# absent sources (-99) give NaN in both columns (fastskymatch.py:55-58)
+	lon, lat = elliptical.offsets(np.array([-99.0, 10.0]), np.array([-99.0, 0.0]), np.array([10.0, -99.0]), np.array([0.0, -99.0]))
+	assert np.isnan(lon).all() and np.isnan(lat).all()
+	# an offset of one arcsecond due east at declination 60: lon' = atan2(cos 60 sin(dra), ...) -> dra cos(dec) to first order
+	lon, lat = elliptical.offsets(15.0, 60.0, 15.0 + 1 / 3600., 60.0)
+	assert abs(lon * 3600 + 0.5) < 1e-6 and abs(lat * 3600) < 1e-5
