@@ -19,18 +19,21 @@ CONFIGS = [
 	('C5 shard (1 of 8 GPUs) 2-way 62500 x 1e8, uniform sky, 5"', ['c3s', '62500', '100000000'], 2, [62500, 100000000]),
 	('C5 whole on ONE GPU 2-way 5e5 x 1e8, uniform sky, 5"', ['c3s', '500000', '100000000'], 2, [500000, 100000000]),
 ]
-print('| configuration | rows M | distance tests | us per pass | rows/s | B_alg (MB) | B_alg / t (GB/s) | of 8 TB/s |')
-print('|---|---|---|---|---|---|---|---|')
+print('| configuration | path | rows M | distance tests | us per pass | rows/s | B_alg (MB) | B_alg / t (GB/s) | of 8 TB/s | stages (us, each bracketed by events) |')
+print('|---|---|---|---|---|---|---|---|---|---|')
 for name, args, k, sizes in CONFIGS:
 	out = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'status_probe.py')] + args, stdout=subprocess.PIPE,
 		stderr=subprocess.STDOUT, universal_newlines=True).stdout
 	st = re.search(r'status \[(\d+), (\d+), (\d+), (\d+)\]', out)
-	tot = re.search(r'total=([0-9.]+) us', out)
+	tot = re.search(r'wall \(no stage events\): ([0-9.]+) us/step', out)
+	path = re.search(r'path: (\w+)', out)
+	stages = re.search(r'stages us/step: (.*?) \|', out)
 	if not st or not tot:
-		print('| %s | failed | | | | | | |' % name)
+		print('| %s | failed | | | | | | | | |' % name)
 		sys.stderr.write(out)
 		continue
 	rows, tests, us = int(st.group(1)), int(st.group(4)), float(tot.group(1))
 	b_alg = 24.0 * sizes[0] + 16.0 * sum(sizes[1:]) + (66.0 if k == 2 else 94.0) * rows
 	rate = b_alg / (us * 1e-6) / 1e9
-	print('| %s | %d | %d | %.1f | %.3g | %.1f | %.0f | %.2f |' % (name, rows, tests, us, rows / (us * 1e-6), b_alg / 1e6, rate, rate / 8000.))
+	print('| %s | %s | %d | %d | %.1f | %.3g | %.1f | %.0f | %.2f | %s |' % (name, path.group(1) if path else '?', rows, tests, us, rows / (us * 1e-6), b_alg / 1e6, rate, rate / 8000.,
+		' '.join(x for x in (stages.group(1) if stages else '').split() if not x.endswith('=0.0'))))
