@@ -5,7 +5,7 @@
 # Three rocprofv3 passes of the same command (kernel trace + stats; FETCH_SIZE; WRITE_SIZE -- the
 # two TCC counters do not fit one pass and --pmc is never combined with other traces) and one
 # plain bench run with the CPU baseline.
-TAG=${1:-r01}
+TAG=${1:-r02}
 cd /tmp && export TMPDIR=/tmp
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/$TAG
