@@ -171,8 +171,11 @@ def atol_for(column, atol=ATOL):
 	return max(atol, ATOL_LOG) if (column in LOGCOLS and atol >= ATOL) else atol
 
 
-def assert_table_matches(table, g, prefix, names, rows=None, rtol=RTOL, atol=ATOL):
-	"""compare a result table (dict of arrays) with golden arrays stored under ``prefix``"""
+def assert_table_matches(table, g, prefix, names, rows=None, rtol=RTOL, atol=ATOL, soak=False):
+	"""compare a result table (dict of arrays) with golden arrays stored under ``prefix``: the
+	contract of the north star, 1e-6 relative (1e-12 absolute) on every floating column.  ``soak``:
+	the wider absolute tolerance of the logarithmic columns (ATOL_LOG) -- for randomized
+	oracle-against-HIP runs only, never for a fixture generated by the reference"""
 	k = len(names)
 	sel = (lambda a: a) if rows is None else (lambda a: np.asarray(a)[rows])
 	idx = np.stack([sel(table[n]) for n in names], axis=1)
@@ -184,7 +187,7 @@ def assert_table_matches(table, g, prefix, names, rows=None, rtol=RTOL, atol=ATO
 			np.testing.assert_allclose(sel(table['Separation_%s_%s' % (names[i], names[j])]),
 				g[prefix + 'sep_%d_%d' % (i, j)], rtol=rtol, atol=1e-9, equal_nan=True)
 	for c in FLOATCOLS:
-		np.testing.assert_allclose(sel(table[c]), g[prefix + c], rtol=rtol, atol=atol_for(c, atol), err_msg=c)
+		np.testing.assert_allclose(sel(table[c]), g[prefix + c], rtol=rtol, atol=(atol_for(c, atol) if soak else atol), err_msg=c)
 
 
 def assert_checksums_match(table, g, prefix, names, rtol=1e-9):

@@ -769,3 +769,39 @@ def test_match_multiple_like_reference_tests(nw, tmp_path, monkeypatch, nfiles, 
 	want = orc.enumerate_tuples(tabs, err, orc.SPHERE, err * 60 * 60)
 	got = np.stack([results[n] for n in table_names], axis=1)
 	np.testing.assert_array_equal(got, want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('k', [2, 3])
+def test_sparse_tails_with_more_rows_than_their_staging_area(nw, k):
+	"""the fused tails stage a workgroup's rows in LDS (640 rows for 256 primaries, k = 2; 952,
+	k = 3) and fall back to writing them directly when a workgroup has more: primaries with three
+	true counterparts each in every secondary catalogue (few CHANCE neighbours, so the sparse
+	path still runs) take that branch; the table must equal the general path's and the oracle's"""
+	from nway_amd import _hip
+	rng = np.random.RandomState(91)
+	n0 = 6000
+	sky = lambda n: (rng.uniform(0, 360, n), np.degrees(np.arcsin(rng.uniform(-0.98, 0.98, n))))
+	a = cat('A', *sky(n0), rng.uniform(0.5, 2, n0), 41252.96)
+	secs = []
+	for name, sig in (('B', 0.3), ('C', 0.5))[:k - 1]:
+		n1 = 60000
+		t = cat(name, *sky(n1), sig * np.ones(n1), 41252.96)
+		for rep in range(3):  # three counterparts for every primary
+			lo = rep * n0
+			t['ra'][lo:lo + n0] = a['ra'] + rng.normal(0, 1, n0) / 3600.
+			t['dec'][lo:lo + n0] = np.clip(a['dec'] + rng.normal(0, 1, n0) / 3600., -90, 90)
+		secs.append(t)
+	tabs = [a] + secs
+	names = [t['name'] for t in tabs]
+	out = {}
+	for slots in (0, -1):
+		res = nw.run_match(tabs, 10., 0.9, link_slots=slots, logger=nw.NullOutputLogger())
+		assert int(res.status[_hip.ST_FLAGS]) == 0 and res.plan.sparse == (slots == 0)
+		assert res.nrows > (4 if k == 2 else 12) * n0 * 0.8
+		out[slots] = dict([(n, res.to_host('idx', c)) for c, n in enumerate(names)] + [('p_i', res.to_host('p_i')), ('p_any', res.to_host('p_any')),
+			('flag', res.to_host('match_flag')), ('bf', res.to_host('log_bf')), ('post', res.to_host('dist_post'))])
+		res.plan.close()
+	for key in out[0]:
+		np.testing.assert_array_equal(out[0][key], out[-1][key], err_msg=key)
+	oracle_vs_hip(nw, tabs, 10., 0.9, names, oracle=orc_c)

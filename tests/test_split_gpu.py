@@ -45,7 +45,7 @@ def catalogues(k, flat):
 	return [a, b, c][:k]
 
 
-def worker(rank, world, port, outfile, k, flat):
+def worker(rank, world, port, outfile, k, flat, capacity=None):
 	os.environ['MASTER_ADDR'] = '127.0.0.1'
 	os.environ['MASTER_PORT'] = str(port)
 	os.environ['HSA_ENABLE_IPC_MODE_LEGACY'] = '0'
@@ -64,7 +64,9 @@ def worker(rank, world, port, outfile, k, flat):
 			n = len(tabs[c]['ra'])
 			cut = [0, int(0.37 * n), n]
 			secs.append(rows(tabs[c], cut[rank], cut[rank + 1]))
-		sm = distributed.SecondarySplitMatch(rows(tabs[0], pb[rank], pb[rank + 1]), secs, 10., 0.9, device=dev)
+		sm = distributed.SecondarySplitMatch(rows(tabs[0], pb[rank], pb[rank + 1]), secs, 10., 0.9, device=dev, capacity=capacity)
+		if capacity is not None:
+			assert sm.capacity > capacity  # the export blocks overflowed and were enlarged, on every rank alike
 		for _ in range(3):  # (repeated steps: the export headers and the scratch copies are recycled)
 			sm.step()
 		total = sm.total_rows()
@@ -84,5 +86,19 @@ def test_secondary_split_on_device(tmp_path, k, flat):
 	tabs = catalogues(k, flat)
 	want = nw.nway_match(tabs, 10., 0.9, logger=nw.NullOutputLogger())
 	assert int(got['total']) == len(want) > 30000
+	for key in want.columns:
+		np.testing.assert_array_equal(got[key], want[key].values, err_msg=key)
+
+
+def test_secondary_split_grows_its_export_blocks(tmp_path):
+	"""export blocks that are too small for the candidates of one peer are flagged by the receiver
+	(NWAYHIP_FLAG_PAIR_OVERFLOW) and the engine comes back with larger ones on every rank"""
+	import nway_amd as nw
+	outfile = str(tmp_path / 'split.npz')
+	mp.spawn(worker, args=(2, free_port(), outfile, 2, False, 64), nprocs=2, join=True)
+	got = np.load(outfile)
+	tabs = catalogues(2, False)
+	want = nw.nway_match(tabs, 10., 0.9, logger=nw.NullOutputLogger())
+	assert int(got['total']) == len(want)
 	for key in want.columns:
 		np.testing.assert_array_equal(got[key], want[key].values, err_msg=key)
