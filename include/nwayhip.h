@@ -127,6 +127,10 @@ int nwayhip_device_count(int* h_count);
 /* fastskymatch.py:26-47  dist(apos, bpos) -> degrees */
 int nwayhip_dist(const double* a_ra, const double* a_dec, const double* b_ra, const double* b_dec,
 	int64_t n, double* out_deg, void* stream);
+/* the same for float32 positions: numpy keeps float32 through every operation and returns float32
+ * (what the reference's match_multiple gets from FITS 'E' coordinate columns) */
+int nwayhip_dist_f32(const float* a_ra, const float* a_dec, const float* b_ra, const float* b_dec,
+	int64_t n, float* out_deg, void* stream);
 /* bayesdistance.py:64-86  log_bf(p, s).  h_sep: host array of ncat*ncat device pointers
  * (row-major, only i<j read), h_sigma: host array of ncat device pointers. */
 int nwayhip_log_bf(int32_t ncat, int64_t n, const double* const* h_sep, const double* const* h_sigma,

@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import ctypes
 import os
+import sys
 
 import numpy
 
@@ -66,6 +67,7 @@ SYMBOLS = {
 	'nwayhip_last_error': (ctypes.c_char_p, []),
 	'nwayhip_device_count': (ctypes.c_int, [ctypes.POINTER(ctypes.c_int)]),
 	'nwayhip_dist': (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _vp, _vp]),
+	'nwayhip_dist_f32': (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _vp, _vp]),
 	'nwayhip_log_bf': (ctypes.c_int, [_i32, _i64, ctypes.POINTER(_vp), ctypes.POINTER(_vp), _vp, _vp]),
 	'nwayhip_log_bf_elliptical': (ctypes.c_int, [_i32, _i64, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp),
 		ctypes.POINTER(_vp), _vp, _vp]),
@@ -158,7 +160,7 @@ def to_device(array, device, dtype=None):
 	dtype = dtype or t.float64
 	if isinstance(array, t.Tensor):
 		return array.to(device=device, dtype=dtype).contiguous()
-	a = numpy.ascontiguousarray(numpy.asarray(array), dtype={t.float64: numpy.float64, t.int32: numpy.int32, t.int64: numpy.int64}[dtype])
+	a = numpy.ascontiguousarray(numpy.asarray(array), dtype={t.float64: numpy.float64, t.float32: numpy.float32, t.int32: numpy.int32, t.int64: numpy.int64}[dtype])
 	return t.from_numpy(a).to(device)
 
 
@@ -364,6 +366,8 @@ def run_plan(sizes, params, catalogues, cap_pairs, cap_rows, device, max_retries
 		plan.enqueue(catalogues)
 		st = plan.read_status()
 		flags = int(st[ST_FLAGS])
+		if os.environ.get('NWAYHIP_TRACE'):
+			sys.stderr.write('run_plan: link_slots %d flags %d rows %d cap_pairs %d cap_rows %d\n' % (plan.link_slots, flags, int(st[ST_ROWS]), cap_pairs, cap_rows))
 		if flags == 0:
 			return plan, st
 		sparse = plan.sparse

@@ -42,12 +42,14 @@
 #include "common.inc"
 #include "sparse.inc"
 #include "front.inc"
+#include "sweepbig.inc"
 #include "scan.inc"
 #include "lists.inc"
 #include "expand.inc"
 #include "rows.inc"
 #include "finish2.inc"
 #include "tail2.inc"
+#include "taild.inc"
 #include "tailk.inc"
 #include "elementwise.inc"
 #include "api.inc"

@@ -16,13 +16,24 @@ from . import _hip
 
 def dist(apos, bpos):
 	"""Angular separation in degrees between positions (ra, dec) in degrees; scalars or
-	equal-length arrays, as fastskymatch.py:26-47.  Computed in float64 on the device
-	(float32 inputs are widened first; the reference would keep float32)."""
+	equal-length arrays, as fastskymatch.py:26-47.  The dtype follows the inputs like numpy's
+	(SURVEY A.8): four float32 arrays are evaluated in float32 and give float32 (k_dist_f32),
+	anything else in float64."""
 	(a_ra, a_dec), (b_ra, b_dec) = apos, bpos
-	arrs = numpy.broadcast_arrays(*[numpy.asarray(x, dtype=float) for x in (a_ra, a_dec, b_ra, b_dec)])
-	shape = arrs[0].shape
 	device = _hip.require_device()
 	t = _hip.torch()
+	given = [numpy.asarray(x) for x in (a_ra, a_dec, b_ra, b_dec)]
+	if all(g.dtype == numpy.float32 and g.ndim > 0 for g in given):
+		arrs = numpy.broadcast_arrays(*given)
+		shape = arrs[0].shape
+		dev = [_hip.to_device(numpy.ascontiguousarray(a).reshape(-1), device, t.float32) for a in arrs]
+		n = int(dev[0].shape[0])
+		out = t.empty(n, dtype=t.float32, device=device)
+		_hip.check(_hip.load().nwayhip_dist_f32(_hip.ptr(dev[0]), _hip.ptr(dev[1]), _hip.ptr(dev[2]), _hip.ptr(dev[3]), n,
+			_hip.ptr(out), _hip.current_stream_ptr(device)))
+		return out.cpu().numpy().reshape(shape)
+	arrs = numpy.broadcast_arrays(*[numpy.asarray(x, dtype=float) for x in (a_ra, a_dec, b_ra, b_dec)])
+	shape = arrs[0].shape
 	dev = [_hip.to_device(numpy.ascontiguousarray(a).reshape(-1), device) for a in arrs]
 	n = int(dev[0].shape[0])
 	out = t.empty(n, dtype=t.float64, device=device)

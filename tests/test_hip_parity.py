@@ -68,6 +68,24 @@ def test_dist_log_bf_posterior_known_answers(nw):
 	assert bd.posterior(1e-3, 2.5) == pytest.approx(0.24043574366935122, rel=1e-12)
 
 
+def test_dist_keeps_float32_like_numpy(nw):
+	"""fastskymatch.py:32-47 on float32 arrays stays float32 in numpy: so does dist() here
+	(k_dist_f32, same operation order); compared with the numpy oracle evaluated in float32 -- the two
+	libm's differ in the last bits of a float32, which the small separations amplify"""
+	rng = np.random.RandomState(12)
+	n = 20000
+	a_ra = rng.uniform(0, 360, n).astype(np.float32)
+	a_dec = np.degrees(np.arcsin(rng.uniform(-1, 1, n))).astype(np.float32)
+	b_ra = (a_ra + rng.normal(0, 1, n).astype(np.float32) * np.float32(0.3)).astype(np.float32)
+	b_dec = np.clip(a_dec + rng.normal(0, 1, n).astype(np.float32) * np.float32(0.3), -90, 90).astype(np.float32)
+	got = nw.match.dist((a_ra, a_dec), (b_ra, b_dec))
+	want = orc.dist((a_ra, a_dec), (b_ra, b_dec))
+	assert got.dtype == np.float32 and want.dtype == np.float32
+	np.testing.assert_allclose(got, want, rtol=2e-4, atol=3e-5)
+	# float64 in, float64 out, as before
+	assert nw.match.dist((a_ra.astype(float), a_dec.astype(float)), (b_ra.astype(float), b_dec.astype(float))).dtype == np.float64
+
+
 def test_ell2_golden(nw):
 	X, R, O = ell_tables()
 	g = golden('ell2')
