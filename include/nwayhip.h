@@ -107,7 +107,7 @@ typedef struct nwayhip_table {
 	int8_t* ncat;
 	double* log_bf;                      /* dist_bayesfactor_uncorrected */
 	double* log_bf_corrected;            /* dist_bayesfactor (== log_bf unless correction CLI); may be NULL */
-	double* prior;                       /* may be NULL where nwayhip_plan_link_slots() says so */
+	double* prior;                       /* may be NULL where nwayhip_plan_path() says so */
 	double* dist_post;
 	double* p_single;                    /* finalize only */
 	double* p_any;                       /* prob_has_match */
@@ -162,11 +162,18 @@ int nwayhip_plan_destroy(nwayhip_plan* plan);
 size_t nwayhip_plan_workspace_bytes(const nwayhip_plan* plan);
 /* slots of the plan's cell table (what to multiply when NWAYHIP_FLAG_REG_OVERFLOW comes back) */
 int64_t nwayhip_plan_table_slots(const nwayhip_plan* plan);
-/* link slots per primary the plan settled on: > 0 = the sparse path runs (direct-mapped cell table,
- * probe inside the sweep, fused tail), 0 = the general path.  On the sparse path with finalize the
- * table's `prior` column may be NULL (nothing reads it after the fused tail); log_bf_corrected may
- * be NULL on every path unless the correction is NWAYHIP_CORRECTION_CLI (it then equals log_bf). */
+/* link slots per primary the plan settled on: > 0 = the sparse front runs (direct-mapped cell table,
+ * probe inside the sweep, candidates in fixed slots of their primaries), 0 = the general path. */
 int32_t nwayhip_plan_link_slots(const nwayhip_plan* plan);
+/* which kernels the plan runs.  SPARSE: the sparse front and a fused tail; with finalize the
+ * table's `prior` column may then be NULL (nothing reads it afterwards).  HYBRID (k >= 3, tens of
+ * links per primary or the script's correction loop): the sparse front feeding the general back
+ * end.  log_bf_corrected may be NULL on every path unless the correction is
+ * NWAYHIP_CORRECTION_CLI (it equals log_bf). */
+#define NWAYHIP_PATH_GENERAL 0
+#define NWAYHIP_PATH_SPARSE 1
+#define NWAYHIP_PATH_HYBRID 2
+int32_t nwayhip_plan_path(const nwayhip_plan* plan);
 /* Enqueue the whole pipeline on `stream`.  d_status: device int64[NWAYHIP_STATUS_WORDS].
  * The workspace's contents may be arbitrary the first time a plan sees it (the plan clears what
  * it needs); between runs of the same plan on the same workspace they must be left alone (by
@@ -181,7 +188,7 @@ int nwayhip_match_enqueue(nwayhip_plan* plan, const nwayhip_catalogue* h_cats, v
  * secondary) is exported to the rank that owns the primary; one all-to-all of the export buffers
  * (the caller's: torch.distributed / RCCL, nway_amd/distributed.py) delivers them; the back half
  * turns what arrived into the links of the rank's own primaries and runs the fused tail on them.
- * Sparse path only (nwayhip_plan_link_slots() > 0).  The plan is created with n[0] = ALL primaries
+ * Sparse path only (nwayhip_plan_path() == NWAYHIP_PATH_SPARSE).  The plan is created with n[0] = ALL primaries
  * and n[c] = the rank's slice sizes; capacities and the table are for the rank's own rows.
  *
  * Export buffer: [destination rank][catalogue c - 1][1 + capacity] records of 32 bytes

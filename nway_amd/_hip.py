@@ -20,6 +20,7 @@ STATUS_WORDS = 32
 ST_ROWS, ST_FLAGS, ST_REGISTRATIONS, ST_TESTS, ST_REGION_NEED = 0, 1, 2, 3, 4
 ST_SURVIVORS, ST_PAIRS, ST_NOTFLAT = 8, 16, 24
 FLAG_PAIR_OVERFLOW, FLAG_ROW_OVERFLOW, FLAG_REG_OVERFLOW, FLAG_SLOT_OVERFLOW, FLAG_LOOKBACK = 1, 2, 4, 8, 16
+PATH_GENERAL, PATH_SPARSE, PATH_HYBRID = 0, 1, 2
 SCHEME_FLAT, SCHEME_SPHERE = 0, 1
 STAGES = 8
 STAGE_NAMES = ['register', 'sweep', 'pairs', 'lists', 'expand', 'rows', 'groups']
@@ -78,6 +79,7 @@ SYMBOLS = {
 	'nwayhip_plan_workspace_bytes': (ctypes.c_size_t, [_vp]),
 	'nwayhip_plan_table_slots': (ctypes.c_int64, [_vp]),
 	'nwayhip_plan_link_slots': (ctypes.c_int32, [_vp]),
+	'nwayhip_plan_path': (ctypes.c_int32, [_vp]),
 	'nwayhip_match_enqueue': (ctypes.c_int, [_vp, ctypes.POINTER(Catalogue), _vp, ctypes.c_size_t, ctypes.POINTER(Table), _vp, _vp]),
 	'nwayhip_split_buffer_bytes': (ctypes.c_size_t, [_vp, _i32, _i64]),
 	'nwayhip_split_front_enqueue': (ctypes.c_int, [_vp, ctypes.POINTER(Catalogue), _vp, ctypes.c_size_t, ctypes.POINTER(Split), _vp, _vp]),
@@ -238,12 +240,14 @@ class MatchPlan(object):
 		self.workspace_bytes = int(self.lib.nwayhip_plan_workspace_bytes(handle))
 		self._table_slots = int(self.lib.nwayhip_plan_table_slots(handle))
 		self.link_slots = int(self.lib.nwayhip_plan_link_slots(handle))
-		self.sparse = self.link_slots > 0
+		self.sparse = self.link_slots > 0   # the sparse front (its overflows send a run to the general path)
+		self.path = int(self.lib.nwayhip_plan_path(handle))
+		self.fused = self.path == PATH_SPARSE
 		self.lean = bool(lean)
 		skip = set()
 		if lean and params.correction == CORRECTION_NONE:
 			skip.add('log_bf_corrected')
-		if lean and self.sparse and params.finalize:
+		if lean and self.fused and params.finalize:
 			skip.add('prior')
 		with t.cuda.device(self.device):
 			self.workspace = t.empty(self.workspace_bytes + 256, dtype=t.uint8, device=self.device)

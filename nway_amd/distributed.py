@@ -387,7 +387,7 @@ class SecondarySplitMatch(object):
 		capacity = self.capacity or max(1024, 4 * max(self.primary_sizes) // self.world + 1024)
 		for attempt in range(6):
 			self.plan = _hip.MatchPlan(sizes, self.params, 65536, cap_rows, self.device, lean=True)
-			if not self.plan.sparse:
+			if not self.plan.fused:
 				self.plan.close()
 				raise _hip.NwayHipError('the secondary-split mode needs the sparse path (few chance neighbours per primary); '
 					'shard dense fields by primary rows (ShardedMatch)')

@@ -1,0 +1,130 @@
+"""The sparse front beyond sparse fields (GPU): dense 2-way fields (tens of links per primary:
+link slots sized by the Poisson tail, candidate-parallel tail), direct-mapped tables too large
+for the LDS of a sweep workgroup (bitmap in L2, folded copy in LDS), k >= 3 with the sparse
+front feeding the general back end, many primaries in one cell.  Each against the C
+restatement of the oracle and against the general path of the library itself."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from goldenutil import ROOT
+
+sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+sys.path.insert(0, ROOT)
+from test_full_size import hip_table, compare, check_properties  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def patch_tables(rng, sizes, half, errors, centre=(150.0, 2.0), frac=0.8):
+	"""catalogues uniform in a square patch; a fraction of the primaries has a counterpart in every secondary"""
+	tabs = []
+	for c, n in enumerate(sizes):
+		ra = rng.uniform(centre[0] - half, centre[0] + half, size=n)
+		dec = rng.uniform(centre[1] - half, centre[1] + half, size=n)
+		err = errors[c] * np.ones(n) if np.isscalar(errors[c]) else errors[c]
+		if c > 0:
+			m = int(frac * sizes[0])
+			slots = rng.choice(n, size=min(m, n), replace=False)
+			m = len(slots)
+			psig = tabs[0]['error'][:m]
+			dec[slots] = tabs[0]['dec'][:m] + rng.normal(0, 1, size=m) * psig / 3600.
+			ra[slots] = tabs[0]['ra'][:m] + rng.normal(0, 1, size=m) * psig / 3600. / np.cos(np.radians(tabs[0]['dec'][:m]))
+		tabs.append(dict(name='T%d' % c, ra=ra, dec=dec, error=err, area=(2 * half)**2, mags=[], maghists=[], magnames=[]))
+	return tabs
+
+
+def both_paths(nw, tabs, radius, completeness=0.9, **options):
+	import nway_oracle_c as orc_c
+	names = [t['name'] for t in tabs]
+	t, status = hip_table(nw, tabs, radius, completeness, **options)
+	assert int(status[1]) == 0
+	check_properties(t, names, len(tabs[0]['ra']))
+	o = orc_c.nway_match(tabs, radius, completeness, correction='cli' if options.get('correction') else 'api')
+	compare(t, o, names)
+	g, _ = hip_table(nw, tabs, radius, completeness, **dict(options, link_slots=-1))
+	assert g['_path'] == 0
+	for key in t:
+		if not key.startswith('_'):
+			np.testing.assert_array_equal(t[key], g[key], err_msg=key)
+	return t
+
+
+def test_dense_two_way_field_stays_on_the_sparse_front():
+	import nway_amd as nw
+	from nway_amd import _hip
+	rng = np.random.default_rng(11)
+	tabs = patch_tables(rng, [3000, 300000], 0.21, [rng.uniform(0.3, 1.5, size=3000), 0.1])  # ~10 chance neighbours per primary
+	t = both_paths(nw, tabs, 5.0)
+	assert t['_path'] == _hip.PATH_SPARSE and t['_link_slots'] > 8
+	assert len(t['ncat']) > 10 * 3000
+
+
+@pytest.mark.parametrize('fold', [19, 20])
+def test_dense_two_way_field_with_a_table_beyond_the_lds(monkeypatch, fold):
+	import nway_amd as nw
+	from nway_amd import _hip
+	monkeypatch.setenv('NWAYHIP_DIRECT_LOG2', '21')
+	monkeypatch.setenv('NWAYHIP_FOLD_LOG2', str(fold))
+	rng = np.random.default_rng(12)
+	tabs = patch_tables(rng, [3001, 200001], 0.21, [rng.uniform(0.3, 1.5, size=3001), 0.1], centre=(0.1, -0.05))  # cells of both signs, odd sizes
+	t = both_paths(nw, tabs, 5.0)
+	assert t['_path'] == _hip.PATH_SPARSE and t['_link_slots'] > 8
+
+
+@pytest.mark.parametrize('fold', [19, 20])
+def test_all_sky_field_with_a_table_beyond_the_lds(monkeypatch, fold):
+	import bench
+	import nway_amd as nw
+	from nway_amd import _hip
+	monkeypatch.setenv('NWAYHIP_DIRECT_LOG2', '22')
+	monkeypatch.setenv('NWAYHIP_FOLD_LOG2', str(fold))
+	prim, sec = bench.make_workload(20000, 1500001, 5)
+	sec = dict(sec, error=0.1 * np.ones(len(sec['ra'])))
+	t = both_paths(nw, [prim, sec], 20.0)
+	assert t['_path'] == _hip.PATH_SPARSE
+
+
+def test_dense_three_way_field_sparse_front_general_back_end():
+	import nway_amd as nw
+	from nway_amd import _hip
+	rng = np.random.default_rng(13)
+	tabs = patch_tables(rng, [3000, 30000, 40000], 0.21, [1.0, 0.1, 0.5])  # ~4 and ~5 chance neighbours per primary
+	t = both_paths(nw, tabs, 10.0)
+	assert t['_path'] == _hip.PATH_HYBRID
+	assert len(t['ncat']) > 15 * 3000
+
+
+def test_three_way_with_the_scripts_correction_sparse_front_general_back_end():
+	import bench
+	import nway_amd as nw
+	from nway_amd import _hip
+	rng = np.random.default_rng(14)
+	prim, a = bench.make_workload(5000, 200000, 7)
+	_, b = bench.make_workload(5000, 150000, 8)
+	m = 3000
+	b['ra'][:m] = prim['ra'][:m]
+	b['dec'][:m] = np.clip(prim['dec'][:m] + rng.normal(0, 0.3, size=m) / 3600., -90, 90)
+	tabs = [prim, dict(a, name='A', error=0.1 * np.ones(len(a['ra']))), dict(b, name='B', error=0.5 * np.ones(len(b['ra'])))]
+	t = both_paths(nw, tabs, 10.0, correction=_hip.CORRECTION_CLI)
+	assert t['_path'] == _hip.PATH_HYBRID
+
+
+def test_many_primaries_in_one_cell():
+	"""more registrations in one cell than a group of the table holds and than one routing pass
+	takes: displaced claims, walks, the routing's repeat"""
+	import nway_amd as nw
+	from nway_amd import _hip
+	rng = np.random.default_rng(15)
+	tabs = patch_tables(rng, [2000, 100000], 0.21, [0.5, 0.1])
+	# 40 primaries within one arcsec of each other, twice; a handful of secondaries among them
+	for at, (ra0, dec0) in ((0, (150.03, 2.01)), (40, (149.9, 1.95))):
+		tabs[0]['ra'][at:at + 40] = ra0 + rng.uniform(0, 1, size=40) / 3600.
+		tabs[0]['dec'][at:at + 40] = dec0 + rng.uniform(0, 1, size=40) / 3600.
+		tabs[1]['ra'][at:at + 7] = ra0 + rng.uniform(-2, 3, size=7) / 3600.
+		tabs[1]['dec'][at:at + 7] = dec0 + rng.uniform(-2, 3, size=7) / 3600.
+	t = both_paths(nw, tabs, 5.0)
+	assert t['_path'] == _hip.PATH_SPARSE
+	both_paths(nw, tabs, 5.0, link_slots=48)

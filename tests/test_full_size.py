@@ -52,13 +52,16 @@ def hip_table(nw, tables, radius, completeness, **options):
 		t[n] = res.to_host('idx', c).astype(np.int64)
 	for p, (i, j) in enumerate(_hip.pair_columns(len(names))):
 		t['Separation_%s_%s' % (names[i], names[j])] = res.to_host('sep', p)
-	for src, dst in (('sep_max', 'Separation_max'), ('log_bf', 'dist_bayesfactor'), ('dist_post', 'dist_post'),
+	# (dist_bayesfactor is the corrected column; it equals log_bf unless the script's correction was asked for)
+	for src, dst in (('sep_max', 'Separation_max'), ('log_bf_corrected' if options.get('correction') else 'log_bf', 'dist_bayesfactor'), ('dist_post', 'dist_post'),
 			('p_single', 'p_single'), ('p_any', 'prob_has_match'), ('p_i', 'prob_this_match')):
 		t[dst] = res.to_host(src)
 	t['ncat'] = res.to_host('ncat').astype(np.int64)
 	t['match_flag'] = res.to_host('match_flag').astype(np.int64)
 	status = res.status
 	t['_sparse'] = res.plan.sparse
+	t['_path'] = res.plan.path
+	t['_link_slots'] = res.plan.link_slots
 	res.plan.close()
 	return t, status
 

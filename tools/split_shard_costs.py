@@ -40,7 +40,7 @@ for world in (1, 2, 4, 8):
 		_hip.DeviceCatalogue(secondary['ra'][sb[0]:sb[1]], secondary['dec'][sb[0]:sb[1]], 0.1, dev)]
 	_, cap_rows = nway_amd._estimate_capacities([int(pb[1])] + [n1], [bench.SKY_AREA] * 2, radius, _hip.SCHEME_SPHERE, True)
 	plan = _hip.MatchPlan([c.n for c in cats], params, 65536, cap_rows, dev, lean=True)
-	assert plan.sparse
+	assert plan.fused
 	capacity = max(1024, 4 * int(pb[1]) // world + 1024)
 	nbytes = plan.split_buffer_bytes(world, capacity)
 	export = torch.zeros(nbytes, dtype=torch.uint8, device=dev)

@@ -75,7 +75,7 @@ cats = [_hip.DeviceCatalogue(t['ra'], t['dec'], np.asarray(t['error'], dtype=flo
 sizes = [c.n for c in cats]
 cap_pairs, cap_rows = nway_amd._estimate_capacities(sizes, [t['area'] for t in tables], radius, scheme, True)
 plan, st = _hip.run_plan(sizes, params, cats, cap_pairs, cap_rows, dev, lean=True)
-print('path:', 'sparse' if plan.sparse else 'general')
+print('path:', ('general', 'sparse', 'hybrid')[plan.path], 'link_slots', plan.link_slots)
 print(config, 'scheme', scheme, 'status', [int(x) for x in st[:4]], 'surv', [int(x) for x in st[8:8 + k - 1]],
 	'pairs', [int(x) for x in st[16:16 + k - 1]], 'notflat', [int(x) for x in st[24:24 + k]])
 import time
