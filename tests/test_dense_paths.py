@@ -46,8 +46,14 @@ def both_paths(nw, tabs, radius, completeness=0.9, **options):
 	compare(t, o, names)
 	g, _ = hip_table(nw, tabs, radius, completeness, **dict(options, link_slots=-1))
 	assert g['_path'] == 0
+	# the same table; groups of more than 64 rows are summed in another order by the general path's
+	# group kernel (rows.inc: group_wave), hence the last bits of their probabilities
 	for key in t:
-		if not key.startswith('_'):
+		if key.startswith('_'):
+			continue
+		if t[key].dtype.kind == 'f' and key in ('prob_has_match', 'prob_this_match'):
+			np.testing.assert_allclose(t[key], g[key], rtol=1e-13, atol=1e-300, equal_nan=True, err_msg=key)
+		else:
 			np.testing.assert_array_equal(t[key], g[key], err_msg=key)
 	return t
 
@@ -87,14 +93,38 @@ def test_all_sky_field_with_a_table_beyond_the_lds(monkeypatch, fold):
 	assert t['_path'] == _hip.PATH_SPARSE
 
 
-def test_dense_three_way_field_sparse_front_general_back_end():
+def test_dense_three_way_field_tuple_parallel_tail():
 	import nway_amd as nw
 	from nway_amd import _hip
 	rng = np.random.default_rng(13)
 	tabs = patch_tables(rng, [3000, 30000, 40000], 0.21, [1.0, 0.1, 0.5])  # ~4 and ~5 chance neighbours per primary
 	t = both_paths(nw, tabs, 10.0)
-	assert t['_path'] == _hip.PATH_HYBRID
+	assert t['_path'] == _hip.PATH_SPARSE and t['_link_slots'] > 8
 	assert len(t['ncat']) > 15 * 3000
+
+
+def test_dense_three_way_field_with_a_crowd(monkeypatch):
+	"""a workgroup of the tuple-parallel tail with more rows than its LDS arrays hold"""
+	import nway_amd as nw
+	from nway_amd import _hip
+	rng = np.random.default_rng(16)
+	tabs = patch_tables(rng, [600, 20000, 20000], 0.21, [1.0, 0.1, 0.5])
+	for c in (1, 2):  # 14 more secondaries of both catalogues around each of the first 40 primaries
+		for i in range(40):
+			at = 1000 + 14 * i
+			tabs[c]['ra'][at:at + 14] = tabs[0]['ra'][i] + rng.normal(0, 2, size=14) / 3600.
+			tabs[c]['dec'][at:at + 14] = tabs[0]['dec'][i] + rng.normal(0, 2, size=14) / 3600.
+	t = both_paths(nw, tabs, 10.0, link_slots=31)
+	assert t['_path'] == _hip.PATH_SPARSE
+
+
+def test_dense_four_way_field_sparse_front_general_back_end():
+	import nway_amd as nw
+	from nway_amd import _hip
+	rng = np.random.default_rng(17)
+	tabs = patch_tables(rng, [2000, 20000, 25000, 15000], 0.21, [1.0, 0.1, 0.5, 0.3])  # 2 .. 3 chance neighbours per primary and catalogue
+	t = both_paths(nw, tabs, 10.0)
+	assert t['_path'] == _hip.PATH_HYBRID
 
 
 def test_three_way_with_the_scripts_correction_sparse_front_general_back_end():
