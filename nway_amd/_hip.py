@@ -375,6 +375,7 @@ def run_plan(sizes, params, catalogues, cap_pairs, cap_rows, device, max_retries
 		if flags == 0:
 			return plan, st
 		sparse = plan.sparse
+		fused = plan.fused
 		slots = plan.table_slots()
 		plan.close()
 		del plan
@@ -412,8 +413,8 @@ def run_plan(sizes, params, catalogues, cap_pairs, cap_rows, device, max_retries
 			reported = int(st[ST_ROWS])
 			if flags & FLAG_PAIR_OVERFLOW:
 				cap_rows = cap_rows * 2             # the links were incomplete: the row count means little
-			elif params.ncat == 2:
-				cap_rows = int(reported * 1.02) + 1024  # exact: one repeat settles it
+			elif params.ncat == 2 or fused:
+				cap_rows = int(reported * 1.02) + 1024  # exact (the fused tails count every row they cannot write): one repeat settles it
 			else:
 				cap_rows = max(cap_rows * 4, int(reported * 1.5) + 1024)  # a level overflowed: lower bound only
 			cap_rows = min(cap_rows, CAPACITY_LIMIT)

@@ -102,3 +102,20 @@ def test_secondary_split_grows_its_export_blocks(tmp_path):
 	assert int(got['total']) == len(want)
 	for key in want.columns:
 		np.testing.assert_array_equal(got[key], want[key].values, err_msg=key)
+
+
+@pytest.mark.parametrize('k,flat', [(2, False), (3, True)])
+def test_secondary_split_with_a_table_beyond_the_lds(tmp_path, monkeypatch, k, flat):
+	"""the large-table sweep (sweepbig.inc) in split mode: survivors flushed by their waves, routed
+	and exported by the workgroup at the end"""
+	import nway_amd as nw
+	outfile = str(tmp_path / 'split.npz')
+	monkeypatch.setenv('NWAYHIP_DIRECT_LOG2', '21')
+	mp.spawn(worker, args=(2, free_port(), outfile, k, flat), nprocs=2, join=True)
+	monkeypatch.delenv('NWAYHIP_DIRECT_LOG2')
+	got = np.load(outfile)
+	tabs = catalogues(k, flat)
+	want = nw.nway_match(tabs, 10., 0.9, logger=nw.NullOutputLogger())
+	assert int(got['total']) == len(want) > 30000
+	for key in want.columns:
+		np.testing.assert_array_equal(got[key], want[key].values, err_msg=key)
