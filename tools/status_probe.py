@@ -65,6 +65,10 @@ else:
 
 k = len(tables)
 dev = torch.device('cuda', 0)
+phases = None
+if os.environ.get('NWAYHIP_PHASES'):  # development: wall-clock stamps of the last fused kernel's workgroups (common.inc: dbg_stamp)
+	phases = torch.zeros(3 * 1024 * 8, dtype=torch.int64, device=dev)
+	os.environ['NWAYHIP_DBG_PTR'] = str(phases.data_ptr())
 log = nway_amd.NullOutputLogger()
 err = radius / 3600.
 scheme = nway_amd.choose_scheme([(t['ra'], t['dec']) for t in tables], err)
@@ -96,3 +100,17 @@ n, ms = plan.profile_read()
 stage_us = [1e3 * m / reps for m in ms]
 print('stages us/step:', ' '.join('%s=%.1f' % (nm, v) for nm, v in zip(_hip.STAGE_NAMES, stage_us)),
 	'| total=%.1f us  rows/s=%.3g' % (sum(stage_us), int(st[0]) / (sum(stage_us) * 1e-6)))
+
+if phases is not None:
+	phases.zero_()
+	plan.enqueue(cats)
+	torch.cuda.synchronize()
+	t = phases.cpu().numpy().reshape(3, 1024, 8)[2].astype(np.float64) * 0.01
+	used = t[:, 0] > 0
+	t = t[used]
+	n = int((t[0] > 0).sum())
+	print('tail kernel, first %d workgroups: us between stamps, mean | max' % used.sum())
+	for i in range(1, n):
+		d = t[:, i] - t[:, i - 1]
+		print('   stamp %d -> %d: %7.2f | %7.2f' % (i - 1, i, d.mean(), d.max()))
+	print('   start of the first to end of the last: %.1f us' % (t[:, n - 1].max() - t[:, 0].min()))
