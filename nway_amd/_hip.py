@@ -365,9 +365,12 @@ def run_plan(sizes, params, catalogues, cap_pairs, cap_rows, device, max_retries
 	report exact needs where a run could count them (links, the rows of a 2-way table), a lower
 	bound otherwise (an expansion level that overflowed ends the run: rows grow fourfold then)."""
 	tries = dict(table=0, path=0, pairs=0, rows=0)
+	attempts = 0
 	while True:
 		plan = MatchPlan(sizes, params, cap_pairs, cap_rows, device, lean=lean)
 		plan.enqueue(catalogues)
+		attempts += 1
+		plan.attempts = attempts  # enqueues it took to settle the capacities (1 = the first guess held)
 		st = plan.read_status()
 		flags = int(st[ST_FLAGS])
 		if os.environ.get('NWAYHIP_TRACE'):

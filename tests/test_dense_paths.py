@@ -158,3 +158,28 @@ def test_many_primaries_in_one_cell():
 	t = both_paths(nw, tabs, 5.0)
 	assert t['_path'] == _hip.PATH_SPARSE
 	both_paths(nw, tabs, 5.0, link_slots=48)
+
+
+@pytest.mark.parametrize('k', [2, 3])
+@pytest.mark.parametrize('dense', [False, True])
+def test_a_row_capacity_that_is_too_small_is_settled_by_one_repeat(monkeypatch, k, dense):
+	"""the fused tails count every row they cannot write: the run that overflowed reports the exact
+	need, the second one holds (no doubling loop)"""
+	import nway_amd as nw
+	from nway_amd import _hip
+	rng = np.random.default_rng(18)
+	sizes = [2000, 200000, 150000][:k] if dense and k == 2 else ([2000, 30000, 25000][:k] if dense else [4000, 50000, 40000][:k])
+	tabs = patch_tables(rng, sizes, 0.21 if dense else 3.0, [1.0, 0.1, 0.5][:k])
+	radius = 5.0 if k == 2 else 10.0
+	want, _ = hip_table(nw, tabs, radius, 0.9)
+	assert want['_path'] == _hip.PATH_SPARSE and (want['_link_slots'] > 8) == dense
+	roomy = nw._estimate_capacities
+	monkeypatch.setattr(nw, '_estimate_capacities', lambda *a, **kw: (roomy(*a, **kw)[0], len(want['ncat']) // 3))
+	res = nw.run_match(tabs, radius, 0.9, logger=nw.NullOutputLogger())
+	monkeypatch.setattr(nw, '_estimate_capacities', roomy)
+	assert res.plan.attempts == 2 and res.plan.path == _hip.PATH_SPARSE
+	assert res.nrows == len(want['ncat'])
+	np.testing.assert_array_equal(res.to_host('idx', k - 1).astype(np.int64), want[tabs[k - 1]['name']])
+	np.testing.assert_array_equal(res.to_host('match_flag').astype(np.int64), want['match_flag'])
+	np.testing.assert_array_equal(res.to_host('p_i'), want['prob_this_match'])
+	res.plan.close()
