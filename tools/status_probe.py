@@ -108,7 +108,7 @@ if phases is not None:
 	t = phases.cpu().numpy().reshape(3, 1024, 8)[2].astype(np.float64) * 0.01
 	used = t[:, 0] > 0
 	t = t[used]
-	n = int((t[0] > 0).sum())
+	n = int((t > 0).all(axis=0).sum())
 	print('tail kernel, first %d workgroups: us between stamps, mean | max' % used.sum())
 	for i in range(1, n):
 		d = t[:, i] - t[:, i - 1]
