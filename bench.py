@@ -169,6 +169,7 @@ def main():
 	ap.add_argument('--cpu-sample', type=int, default=1000000, help='secondaries in the numpy leg of the CPU baseline (0 = no CPU baseline at all)')
 	ap.add_argument('--event-every', type=int, default=8, help='every n-th sweep launch of the timed region carries a HIP event pair')
 	ap.add_argument('--profile-stages', action='store_true', help='also time every stage (adds event records to the region)')
+	ap.add_argument('--two-pipelines', type=int, default=1, help='also time the steps alternating over two independent pipelines (reported beside, never as, `value`); 0 = skip')
 	ap.add_argument('--streams', type=int, default=int(os.environ.get('NWAY_BENCH_STREAMS', '1')),
 		help='independent pipelines (own workspace, own output table, own HIP stream) the steps alternate over')
 	args = ap.parse_args()
@@ -369,6 +370,28 @@ def main():
 				pass_note='SURVEY 8(d): every input column once + 66 B per row, divided by the WHOLE step (all launches and the gaps between them); rank 0'))
 		if io is not None:
 			out['io'] = io
+		if engine is None and len(plans) == 1 and args.two_pipelines:
+			# supplementary, never `value`: the same steps alternating over TWO independent pipelines
+			# (plan + workspace + table + stream each), so that the latency-bound registration and tail
+			# of one pass run beside those of the other (the sweeps cannot share a CU: 156 KB of LDS each)
+			second = _hip.MatchPlan(sizes, params, plan.cap_pairs, plan.cap_rows, device, lean=True)
+			pair, lanes = [plan, second], [torch.cuda.Stream(device=device) for _ in range(2)]
+
+			def two(n):
+				for j in range(n):
+					with torch.cuda.stream(lanes[j % 2]):
+						pair[j % 2].enqueue([cats[0], sec_copies[j % len(sec_copies)]])
+			two(args.warmup + 2)
+			torch.cuda.synchronize(device)
+			t1 = time.perf_counter()
+			two(args.steps)
+			torch.cuda.synchronize(device)
+			ms2 = (time.perf_counter() - t1) * 1e3 / args.steps
+			assert int(second.read_status()[_hip.ST_FLAGS]) == 0 and int(second.read_status()[_hip.ST_ROWS]) == rows_per_step
+			out['two_pipelines'] = dict(streams=2, ms_per_step=ms2, value=rows_per_step / (ms2 * 1e-3),
+				pass_frac=p_bytes / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS,
+				note='supplementary: the same passes, two in flight on separate HIP streams; `value` above is one pass at a time')
+			second.close()
 		if args.profile_stages:
 			out['stages_ms'] = dict((name, ms[i] / max(launches[i], 1) * (launches[i] / float(args.steps)))
 				for i, name in enumerate(_hip.STAGE_NAMES))
