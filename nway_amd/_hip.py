@@ -243,6 +243,7 @@ class MatchPlan(object):
 		self.sparse = self.link_slots > 0   # the sparse front (its overflows send a run to the general path)
 		self.path = int(self.lib.nwayhip_plan_path(handle))
 		self.fused = self.path == PATH_SPARSE
+		self.attempts = 1  # (run_plan: enqueues it took to settle the capacities)
 		self.lean = bool(lean)
 		skip = set()
 		if lean and params.correction == CORRECTION_NONE:
