@@ -72,13 +72,15 @@ typedef struct nwayhip_match_params {
 	int32_t correction;                  /* NWAYHIP_CORRECTION_* */
 	int32_t finalize;                    /* 1: also run the per-primary group statistics with
 	                                        total = dist_bayesfactor (no magnitude biases) */
-	int32_t link_slots;                  /* sparse path (any number of catalogues): the links of every
-	                                        secondary catalogue are kept in this many fixed slots per primary
-	                                        (at most 8), found by the sweep itself, and everything after them
-	                                        is fused into one launch.  0 = decide from the densities (8 slots
-	                                        if every catalogue expects < 0.5 chance neighbours per primary and
-	                                        the primaries' cells fit the direct-mapped table), -1 = never,
-	                                        > 0 = force where possible */
+	int32_t link_slots;                  /* sparse front (any number of catalogues; needs radius_filter): the
+	                                        links of every secondary catalogue are kept in this many fixed
+	                                        slots per primary (at most 64), found by the sweep itself.
+	                                        0 = decide from the densities: 8 slots where every catalogue
+	                                        expects < 0.5 chance neighbours lambda per primary, else
+	                                        lambda + 6 sqrt(lambda) + 6, if that is at most 64 and the
+	                                        primaries' cells fit the direct-mapped table; -1 = never (the
+	                                        general path); > 0 = force where possible.  What follows the
+	                                        front: nwayhip_plan_path() */
 	double err_deg;                      /* cell size: match_radius / 60. / 60 (__init__.py:128) */
 	double radius_arcsec;                /* match_radius */
 	double prob_ratio_secondary;         /* __init__.py:33 */
