@@ -3,7 +3,7 @@
     python tools/status_probe.py [c3s|c3d|c4s|c4d] [n_primary] [n_secondary] [radius]
 
 c3s: 2-way uniform sky (bench workload)      c3d: 2-way dense 6 deg^2 patch (flat cells)
-c4s: 3-way uniform sky, 1e5 x 1e6 x 1e6     c4d: 3-way dense 8 deg^2 patch
+c4s: 3-way uniform sky, 1e5 x 1e6 x 1e6     c4d: 3-way dense 8 deg^2 patch     c6d: 4-way dense (hybrid path)
 """
 import os
 import sys
@@ -21,6 +21,7 @@ config = args.pop(0) if args and not args[0].isdigit() else 'c3s'
 n0 = int(args[0]) if len(args) > 0 else 100000
 n1 = int(args[1]) if len(args) > 1 else (10000000 if config.startswith('c3') else 1000000)
 radius = float(args[2]) if len(args) > 2 else (5.0 if config.startswith('c3') else 10.0)
+force_slots = int(os.environ.get('PROBE_LINK_SLOTS', '0'))
 rng = np.random.default_rng(3)
 
 
@@ -60,6 +61,11 @@ elif config == 'c4d':
 	psig = np.ones(n0)
 	prim = patch_catalogue('P', n0, 1.42, psig)
 	tables = [prim, patch_catalogue('A', n1, 1.42, 0.1, prim, 0.8, psig), patch_catalogue('B', n1, 1.42, 0.5, prim, 0.6, psig)]
+elif config == 'c6d':  # 4-way dense: 1e5 x 5e5 x 5e5 x 5e5 in 8 deg^2 (the hybrid path)
+	psig = np.ones(n0)
+	prim = patch_catalogue('P', n0, 1.42, psig)
+	tables = [prim, patch_catalogue('A', n1 // 2, 1.42, 0.1, prim, 0.8, psig), patch_catalogue('B', n1 // 2, 1.42, 0.5, prim, 0.6, psig),
+		patch_catalogue('C', n1 // 2, 1.42, 0.3, prim, 0.5, psig)]
 else:
 	raise SystemExit('unknown config ' + config)
 
@@ -74,7 +80,7 @@ err = radius / 3600.
 scheme = nway_amd.choose_scheme([(t['ra'], t['dec']) for t in tables], err)
 dens, dp = nway_amd._compute_source_densities(tables, log)
 comp = nway_amd._completeness_vector(0.9, k)
-params = _hip.make_params(k, scheme, radius, err, dens, dp, nway_amd._prior_table(dens, dp, comp))
+params = _hip.make_params(k, scheme, radius, err, dens, dp, nway_amd._prior_table(dens, dp, comp), link_slots=force_slots)
 cats = [_hip.DeviceCatalogue(t['ra'], t['dec'], np.asarray(t['error'], dtype=float), dev) for t in tables]
 sizes = [c.n for c in cats]
 cap_pairs, cap_rows = nway_amd._estimate_capacities(sizes, [t['area'] for t in tables], radius, scheme, True)
