@@ -80,7 +80,8 @@ err = radius / 3600.
 scheme = nway_amd.choose_scheme([(t['ra'], t['dec']) for t in tables], err)
 dens, dp = nway_amd._compute_source_densities(tables, log)
 comp = nway_amd._completeness_vector(0.9, k)
-params = _hip.make_params(k, scheme, radius, err, dens, dp, nway_amd._prior_table(dens, dp, comp), link_slots=force_slots)
+params = _hip.make_params(k, scheme, radius, err, dens, dp, nway_amd._prior_table(dens, dp, comp), link_slots=force_slots,
+	correction=int(os.environ.get('PROBE_CORRECTION', '0')))
 cats = [_hip.DeviceCatalogue(t['ra'], t['dec'], np.asarray(t['error'], dtype=float), dev) for t in tables]
 sizes = [c.n for c in cats]
 cap_pairs, cap_rows = nway_amd._estimate_capacities(sizes, [t['area'] for t in tables], radius, scheme, True)
