@@ -168,9 +168,9 @@ int64_t nwayhip_plan_table_slots(const nwayhip_plan* plan);
  * probe inside the sweep, candidates in fixed slots of their primaries), 0 = the general path. */
 int32_t nwayhip_plan_link_slots(const nwayhip_plan* plan);
 /* which kernels the plan runs.  SPARSE: the sparse front and a fused tail; with finalize the
- * table's `prior` column may then be NULL (nothing reads it afterwards).  HYBRID (k >= 3, tens of
- * links per primary or the script's correction loop): the sparse front feeding the general back
- * end.  log_bf_corrected may be NULL on every path unless the correction is
+ * table's `prior` column may then be NULL (nothing reads it afterwards).  HYBRID (k >= 4 with tens
+ * of links per primary or the script's correction loop): the sparse front feeding the general
+ * back end.  log_bf_corrected may be NULL on every path unless the correction is
  * NWAYHIP_CORRECTION_CLI (it equals log_bf). */
 #define NWAYHIP_PATH_GENERAL 0
 #define NWAYHIP_PATH_SPARSE 1

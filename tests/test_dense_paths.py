@@ -127,7 +127,7 @@ def test_dense_four_way_field_sparse_front_general_back_end():
 	assert t['_path'] == _hip.PATH_HYBRID
 
 
-def test_three_way_with_the_scripts_correction_sparse_front_general_back_end():
+def test_three_way_with_the_scripts_correction_in_the_fused_tails():
 	import bench
 	import nway_amd as nw
 	from nway_amd import _hip
@@ -138,6 +138,37 @@ def test_three_way_with_the_scripts_correction_sparse_front_general_back_end():
 	b['ra'][:m] = prim['ra'][:m]
 	b['dec'][:m] = np.clip(prim['dec'][:m] + rng.normal(0, 0.3, size=m) / 3600., -90, 90)
 	tabs = [prim, dict(a, name='A', error=0.1 * np.ones(len(a['ra']))), dict(b, name='B', error=0.5 * np.ones(len(b['ra'])))]
+	t = both_paths(nw, tabs, 10.0, correction=_hip.CORRECTION_CLI)
+	assert t['_path'] == _hip.PATH_SPARSE and t['_link_slots'] == 8   # k_tailk<3> applies the correction itself
+	# a dense field: the tuple-parallel tail does
+	rng = np.random.default_rng(19)
+	dense = patch_tables(rng, [3000, 30000, 40000], 0.21, [1.0, 0.1, 0.5])
+	t = both_paths(nw, dense, 10.0, correction=_hip.CORRECTION_CLI)
+	assert t['_path'] == _hip.PATH_SPARSE and t['_link_slots'] > 8
+	# ... also where a workgroup has more rows than its LDS arrays
+	crowd = patch_tables(rng, [600, 20000, 20000], 0.21, [1.0, 0.1, 0.5])
+	for c in (1, 2):
+		for i in range(40):
+			at = 1000 + 14 * i
+			crowd[c]['ra'][at:at + 14] = crowd[0]['ra'][i] + rng.normal(0, 2, size=14) / 3600.
+			crowd[c]['dec'][at:at + 14] = crowd[0]['dec'][i] + rng.normal(0, 2, size=14) / 3600.
+	t = both_paths(nw, crowd, 10.0, correction=_hip.CORRECTION_CLI, link_slots=31)
+	assert t['_path'] == _hip.PATH_SPARSE
+
+
+def test_four_way_with_the_scripts_correction_sparse_front_general_back_end():
+	import bench
+	import nway_amd as nw
+	from nway_amd import _hip
+	rng = np.random.default_rng(20)
+	prim, a = bench.make_workload(4000, 150000, 9)
+	tabs = [prim, dict(a, name='A', error=0.1 * np.ones(len(a['ra'])))]
+	for name, n, seed, sig in (('B', 120000, 10, 0.5), ('C', 100000, 11, 0.3)):
+		_, b = bench.make_workload(4000, n, seed)
+		m = 2500
+		b['ra'][:m] = prim['ra'][:m]
+		b['dec'][:m] = np.clip(prim['dec'][:m] + rng.normal(0, 0.3, size=m) / 3600., -90, 90)
+		tabs.append(dict(b, name=name, error=sig * np.ones(n)))
 	t = both_paths(nw, tabs, 10.0, correction=_hip.CORRECTION_CLI)
 	assert t['_path'] == _hip.PATH_HYBRID
 
