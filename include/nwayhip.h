@@ -46,6 +46,8 @@ extern "C" {
 #define NWAYHIP_ST_TESTS 3               /* great-circle distance tests executed (M0') */
 #define NWAYHIP_ST_REGION_NEED 4         /* with NWAYHIP_FLAG_PAIR_OVERFLOW: links one workgroup wanted to keep, if that
                                             (and not the total) is what did not fit: come back with link_region_min */
+#define NWAYHIP_ST_SLOT_NEED 5           /* with NWAYHIP_FLAG_SLOT_OVERFLOW: the most candidates of one primary and catalogue (0: the
+                                            overflow was not of that kind); link_slots = that many, if <= 64, keeps the sparse front */
 #define NWAYHIP_ST_SURVIVORS 8           /* + c: secondaries of catalogue c passing the cell filter */
 #define NWAYHIP_ST_PAIRS 16              /* + c: (primary, secondary) links of catalogue c */
 #define NWAYHIP_ST_NOTFLAT 24            /* + c: 1 if catalogue c violates the flat-cell condition */
@@ -53,7 +55,7 @@ extern "C" {
 #define NWAYHIP_FLAG_PAIR_OVERFLOW 1     /* cap_pairs too small: results invalid, retry larger */
 #define NWAYHIP_FLAG_ROW_OVERFLOW 2      /* cap_rows too small: results invalid, retry larger */
 #define NWAYHIP_FLAG_REG_OVERFLOW 4      /* registration table too small */
-#define NWAYHIP_FLAG_SLOT_OVERFLOW 8     /* a primary has more links than link_slots: repeat with link_slots = -1 */
+#define NWAYHIP_FLAG_SLOT_OVERFLOW 8     /* a primary has more links than link_slots: repeat with more (NWAYHIP_ST_SLOT_NEED) or link_slots = -1 */
 #define NWAYHIP_FLAG_LOOKBACK 16         /* the single-pass scan timed out: repeat with link_slots = -1 */
 
 typedef struct nwayhip_catalogue {

@@ -17,7 +17,8 @@ from . import build as _build
 MAXCAT = 8
 MAXPAIR = 28
 STATUS_WORDS = 32
-ST_ROWS, ST_FLAGS, ST_REGISTRATIONS, ST_TESTS, ST_REGION_NEED = 0, 1, 2, 3, 4
+ST_ROWS, ST_FLAGS, ST_REGISTRATIONS, ST_TESTS, ST_REGION_NEED, ST_SLOT_NEED = 0, 1, 2, 3, 4, 5
+LINK_SLOTS_CAP = 64
 ST_SURVIVORS, ST_PAIRS, ST_NOTFLAT = 8, 16, 24
 FLAG_PAIR_OVERFLOW, FLAG_ROW_OVERFLOW, FLAG_REG_OVERFLOW, FLAG_SLOT_OVERFLOW, FLAG_LOOKBACK = 1, 2, 4, 8, 16
 PATH_GENERAL, PATH_SPARSE, PATH_HYBRID = 0, 1, 2
@@ -365,7 +366,7 @@ def run_plan(sizes, params, catalogues, cap_pairs, cap_rows, device, max_retries
 	may need the general path, a larger link region AND several row doublings): the status words
 	report exact needs where a run could count them (links, the rows of a 2-way table), a lower
 	bound otherwise (an expansion level that overflowed ends the run: rows grow fourfold then)."""
-	tries = dict(table=0, path=0, pairs=0, rows=0)
+	tries = dict(table=0, path=0, pairs=0, rows=0, slots=0)
 	attempts = 0
 	while True:
 		plan = MatchPlan(sizes, params, cap_pairs, cap_rows, device, lean=lean)
@@ -388,6 +389,13 @@ def run_plan(sizes, params, catalogues, cap_pairs, cap_rows, device, max_retries
 			tries[kind] += 1
 			if tries[kind] > max_retries:
 				raise NwayHipError('match table capacity could not be settled (%s, %d attempts; status flags %d)' % (kind, max_retries, flags))
+		need = int(st[ST_SLOT_NEED])
+		if flags & FLAG_SLOT_OVERFLOW and not flags & (FLAG_LOOKBACK | FLAG_REG_OVERFLOW) and 0 < need <= LINK_SLOTS_CAP and tries['slots'] < 2:
+			# a primary with more candidates than the slots sized for the mean density (a clustered
+			# field): the run counted them; once or twice more with that many slots before giving the sparse front up
+			tries['slots'] += 1
+			params.link_slots = min(LINK_SLOTS_CAP, need + (need >> 3) + 1)
+			continue
 		if flags & (FLAG_SLOT_OVERFLOW | FLAG_LOOKBACK) or (flags & FLAG_REG_OVERFLOW and sparse):
 			# the sparse path does not fit this input (a primary with more candidates than slots,
 			# primaries piled up in a few cells): repeat on the general path

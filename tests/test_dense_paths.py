@@ -214,3 +214,22 @@ def test_a_row_capacity_that_is_too_small_is_settled_by_one_repeat(monkeypatch, 
 	np.testing.assert_array_equal(res.to_host('match_flag').astype(np.int64), want['match_flag'])
 	np.testing.assert_array_equal(res.to_host('p_i'), want['prob_this_match'])
 	res.plan.close()
+
+
+@pytest.mark.parametrize('k', [2, 3])
+def test_a_cluster_with_more_candidates_than_slots_keeps_the_sparse_front(k):
+	"""slots are sized for the mean density; a few primaries in a cluster have more candidates:
+	the run that overflowed reports how many, the next one has that many slots (no general path)"""
+	import nway_amd as nw
+	from nway_amd import _hip
+	rng = np.random.default_rng(21)
+	tabs = patch_tables(rng, [3000, 40000, 30000][:k], 3.0, [1.0, 0.1, 0.5][:k])   # ~0.01 chance neighbours per primary
+	for c in range(1, k):
+		for i in range(30):  # a dozen secondaries within a few arcsec of each of the first 30 primaries
+			at = 5000 + 12 * i
+			tabs[c]['ra'][at:at + 12] = tabs[0]['ra'][i] + rng.normal(0, 1.5, size=12) / 3600.
+			tabs[c]['dec'][at:at + 12] = tabs[0]['dec'][i] + rng.normal(0, 1.5, size=12) / 3600.
+	res = nw.run_match(tabs, 8.0, 0.9, logger=nw.NullOutputLogger())
+	assert res.plan.path == _hip.PATH_SPARSE and res.plan.attempts == 2 and 8 < res.plan.link_slots <= 20
+	res.plan.close()
+	both_paths(nw, tabs, 8.0)

@@ -577,8 +577,8 @@ def test_sparse_fields_golden(nw):
 
 def test_sparse_fast_path_and_its_fallback(nw):
 	"""2-way sparse inputs take the fused tail (links in fixed slots + single-pass scan); a primary
-	with more links than slots makes the run fall back to the general path; both paths and the
-	general path forced from the start give the identical table"""
+	with more links than slots makes the run report how many it has and come back with that many
+	slots; both and the general path forced from the start give the identical table"""
 	from nway_amd import _hip
 	rng = np.random.RandomState(31)
 	n0, n1 = 70000, 400000
@@ -593,7 +593,7 @@ def test_sparse_fast_path_and_its_fallback(nw):
 		res = nw.run_match([a, b], 10., 0.9, link_slots=slots, logger=nw.NullOutputLogger())
 		assert int(res.status[_hip.ST_FLAGS]) == 0
 		if slots == 2:
-			assert res.plan.params.link_slots == -1  # fell back
+			assert res.plan.attempts == 2 and res.plan.link_slots == 6 and res.plan.sparse  # five candidates counted, six slots the second time
 		tables[slots] = dict(idx1=res.to_host('idx', 1), p_i=res.to_host('p_i'), p_any=res.to_host('p_any'), flag=res.to_host('match_flag'),
 			bf=res.to_host('log_bf'), gs=res.plan.cols['group_start'].cpu().numpy())
 		res.plan.close()
@@ -604,8 +604,8 @@ def test_sparse_fast_path_and_its_fallback(nw):
 
 
 def test_sparse_fast_path_three_way(nw):
-	"""k = 3 on sparse inputs: the links of a primary stay in fixed slots (no link lists) and are
-	ordered by one small kernel; too many links for the slots -> general path; identical tables"""
+	"""k = 3 on sparse inputs: the links of a primary stay in fixed slots (no link lists); too many
+	links for the slots -> once more with as many as were counted; identical tables"""
 	from nway_amd import _hip
 	rng = np.random.RandomState(33)
 	n0, n1, n2 = 30000, 200000, 150000
@@ -623,7 +623,7 @@ def test_sparse_fast_path_three_way(nw):
 	for slots in (0, 2, -1):
 		res = nw.run_match([a, b, c], 10., 0.9, link_slots=slots, logger=nw.NullOutputLogger())
 		assert int(res.status[_hip.ST_FLAGS]) == 0
-		assert (res.plan.params.link_slots == -1) == (slots != 0)
+		assert res.plan.sparse == (slots != -1) and res.plan.attempts == (2 if slots == 2 else 1)
 		tables[slots] = dict(idx1=res.to_host('idx', 1), idx2=res.to_host('idx', 2), p_i=res.to_host('p_i'),
 			flag=res.to_host('match_flag'), bf=res.to_host('log_bf'), gs=res.plan.cols['group_start'].cpu().numpy())
 		res.plan.close()
