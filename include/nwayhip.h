@@ -171,8 +171,7 @@ int64_t nwayhip_plan_table_slots(const nwayhip_plan* plan);
 int32_t nwayhip_plan_link_slots(const nwayhip_plan* plan);
 /* which kernels the plan runs.  SPARSE: the sparse front and a fused tail; with finalize the
  * table's `prior` column may then be NULL (nothing reads it afterwards).  HYBRID (k >= 4 with tens
- * of links per primary or the script's correction loop): the sparse front feeding the general
- * back end.  log_bf_corrected may be NULL on every path unless the correction is
+ * of links per primary): the sparse front feeding the general back end.  log_bf_corrected may be NULL on every path unless the correction is
  * NWAYHIP_CORRECTION_CLI (it equals log_bf). */
 #define NWAYHIP_PATH_GENERAL 0
 #define NWAYHIP_PATH_SPARSE 1

@@ -156,7 +156,7 @@ def test_three_way_with_the_scripts_correction_in_the_fused_tails():
 	assert t['_path'] == _hip.PATH_SPARSE
 
 
-def test_four_way_with_the_scripts_correction_sparse_front_general_back_end():
+def test_four_way_with_the_scripts_correction_fused_and_on_the_general_back_end(monkeypatch):
 	import bench
 	import nway_amd as nw
 	from nway_amd import _hip
@@ -170,6 +170,14 @@ def test_four_way_with_the_scripts_correction_sparse_front_general_back_end():
 		b['dec'][:m] = np.clip(prim['dec'][:m] + rng.normal(0, 0.3, size=m) / 3600., -90, 90)
 		tabs.append(dict(b, name=name, error=sig * np.ones(n)))
 	t = both_paths(nw, tabs, 10.0, correction=_hip.CORRECTION_CLI)
+	assert t['_path'] == _hip.PATH_SPARSE   # k_tailk<4, true>: one lane per primary corrects its rows
+	monkeypatch.setenv('NWAYHIP_FUSED_CORRECTION', '0')
+	t = both_paths(nw, tabs, 10.0, correction=_hip.CORRECTION_CLI)
+	assert t['_path'] == _hip.PATH_HYBRID   # the same with k_correct behind the general back end
+	monkeypatch.delenv('NWAYHIP_FUSED_CORRECTION')
+	# a dense 4-way field with the correction: hybrid
+	dense = patch_tables(rng, [1500, 15000, 20000, 12000], 0.21, [1.0, 0.1, 0.5, 0.3])
+	t = both_paths(nw, dense, 10.0, correction=_hip.CORRECTION_CLI)
 	assert t['_path'] == _hip.PATH_HYBRID
 
 
