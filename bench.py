@@ -169,6 +169,7 @@ def main():
 	ap.add_argument('--cpu-sample', type=int, default=1000000, help='secondaries in the numpy leg of the CPU baseline (0 = no CPU baseline at all)')
 	ap.add_argument('--event-every', type=int, default=8, help='every n-th sweep launch of the timed region carries a HIP event pair')
 	ap.add_argument('--profile-stages', action='store_true', help='also time every stage (adds event records to the region)')
+	ap.add_argument('--prewarm', type=int, default=200, help='untimed steps before the W warm-up steps: the first ~10 ms after an idle period run at lower clocks (20 steps right after start-up: 82 us each, after 200: 78.5)')
 	ap.add_argument('--two-pipelines', type=int, default=1, help='also time the steps alternating over two independent pipelines (reported beside, never as, `value`); 0 = skip')
 	ap.add_argument('--streams', type=int, default=int(os.environ.get('NWAY_BENCH_STREAMS', '1')),
 		help='independent pipelines (own workspace, own output table, own HIP stream) the steps alternate over')
@@ -294,7 +295,7 @@ def main():
 			dist.barrier()
 			torch.cuda.synchronize(device)
 
-	for _ in range(args.warmup):
+	for _ in range(max(args.prewarm, 0) + args.warmup):
 		step()
 	mask = (1 << _hip.STAGES) - 1 if args.profile_stages else (1 << 1)
 	for pl in plans:
@@ -360,7 +361,7 @@ def main():
 				rows_per_step=rows_per_step, distance_tests_per_step_rank0=int(st[_hip.ST_TESTS]),
 				survivors_per_step_rank0=int(st[_hip.ST_SURVIVORS]), registrations_rank0=int(st[_hip.ST_REGISTRATIONS]),
 				parallelism=('secondary-stream slices x%d + candidate routing' % world) if strong else ('primary-row shards x%d' % world),
-				streams=len(plans), secondary_buffers=(len(sec_copies) if engine is None else 1),
+				streams=len(plans), secondary_buffers=(len(sec_copies) if engine is None else 1), prewarm_steps=max(args.prewarm, 0),
 				setup_exchange=(None if engine is None else dict(seconds=engine.setup_seconds, bytes=engine.gathered_bytes,
 					note='one-time exchange at set-up (RCCL), outside the timed steps'))),
 			roofline=dict(bound='hbm', kernel='k_sweep', achieved=achieved, peak=HBM_PEAK_GBS, unit='GB/s',
