@@ -105,6 +105,27 @@ def test_random_configurations(seed):
 	assert rows >= len(tabs[0]['ra'])
 
 
+@pytest.mark.parametrize('seed', range(40, 64))
+@pytest.mark.parametrize('forced', ['large-table', 'dense-tails'])
+def test_random_configurations_on_forced_paths(monkeypatch, seed, forced):
+	"""the same on paths these small inputs would not take by themselves: a direct-mapped table beyond
+	the LDS of a sweep workgroup (k_sweep_big), 24 slots per primary (candidate- / tuple-parallel
+	tails, the general back end fed from the slots)"""
+	import nway_amd as nw
+	monkeypatch.setenv('NWAYHIP_DIRECT_LOG2', '21')
+	if forced == 'dense-tails':
+		monkeypatch.setenv('NWAYHIP_LINK_SLOTS', '24')
+		monkeypatch.setenv('NWAYHIP_FOLD_LOG2', '19')
+	rng = np.random.default_rng(1000 + seed)
+	k = int(rng.integers(2, 6))
+	tabs, radius = (flat_case if seed % 2 == 0 else sphere_case)(rng, k)
+	if seed % 2 == 1 and k > 4:
+		tabs = tabs[:4]
+	comp = float(rng.choice([1.0, 0.9, 0.5]))
+	rows = compare(nw, tabs, radius, comp, 'cli' if seed % 3 == 0 else 'api', f32=(seed % 5 == 0))
+	assert rows >= len(tabs[0]['ra'])
+
+
 @pytest.mark.parametrize('k', [6, 7, 8])
 @pytest.mark.parametrize('kind', ['flat', 'sphere'])
 def test_many_catalogues(k, kind):
