@@ -33,7 +33,11 @@ Prints ONE JSON line on rank 0 (contract in the task description) with these ext
   cpu_baseline the C restatement of the oracle (oracle/nway_oracle.c, "port") timed on this host:
                all cores (OpenMP build), one core, and the numpy oracle on one thread.
   check        the table of the last timed step against the CPU table of the same workload.
-  io           host -> device upload of the inputs and device -> host download of the table.
+  io           host -> device upload of the inputs and device -> host download of the table; e2e_ms:
+               host arrays in -> table on the host, everything included (upload + pass + download).
+roofline also carries two ceilings measured on this box in this run: read_peak (the sweep's own
+access pattern with nothing behind the loads, nwayhip_read_probe) and copy_peak (device-to-device
+copy of one column, bytes read + written).
 """
 from __future__ import division, print_function
 
@@ -122,6 +126,64 @@ def cpu_baseline(primary, secondary, radius, completeness, numpy_sample):
 		reference_note='the reference itself (pure Python, one thread; it cannot travel to the GPU box) measured in the build container '
 			'on its own fixtures: 8.4e4 rows/s (tests/elltest 2-way, 37 706 rows in 0.45 s), 5.3e4 rows/s (3-way, 450 435 rows in 8.5 s)')
 	return out, table
+
+
+def measured_ceilings(sec_copies, device, reps=30):
+	"""what this box's memory system gives, measured in this run ('also measure an on-box copy
+	kernel'): the sweep's stream with nothing behind the loads (read only, alternating over the copies of
+	the secondary catalogue so that the Infinity Cache does not serve it), and a device-to-device copy"""
+	import ctypes
+	import torch
+	from nway_amd import _hip
+	lib = _hip.load()
+	n = sec_copies[0].n
+	out = torch.zeros(1024, dtype=torch.float64, device=device)
+	stream = _hip.current_stream_ptr(device)
+
+	def probe(i):
+		c = sec_copies[i % len(sec_copies)]
+		_hip.check(lib.nwayhip_read_probe(_hip.ptr(c.ra), _hip.ptr(c.dec), n, _hip.ptr(out), 256, stream))
+	for i in range(5):
+		probe(i)
+	e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+	e0.record()
+	for i in range(reps):
+		probe(i)
+	e1.record()
+	e1.synchronize()
+	read_gbs = 16.0 * n * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
+	dst = torch.empty_like(sec_copies[0].ra)
+	for i in range(3):
+		dst.copy_(sec_copies[i % len(sec_copies)].ra)
+	e0.record()
+	for i in range(reps):
+		dst.copy_((sec_copies[i % len(sec_copies)].ra, sec_copies[i % len(sec_copies)].dec)[i & 1])
+	e1.record()
+	e1.synchronize()
+	copy_gbs = 16.0 * n * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
+	return read_gbs, copy_gbs
+
+
+def end_to_end(tables, radius, completeness, device, reps=3):
+	"""host arrays in -> match table on the host: upload, one pass, download of every column; the best of
+	`reps` (the first carries the allocations)"""
+	import torch
+	import nway_amd
+	best = None
+	for _ in range(reps):
+		torch.cuda.synchronize(device)
+		t0 = time.perf_counter()
+		res = nway_amd.run_match(tables, radius, completeness, device=device, lean=True)
+		t1 = time.perf_counter()
+		m = res.nrows
+		cols = [res.to_host('idx', c) for c in range(len(tables))] + [res.to_host('sep', 0)]
+		cols += [res.to_host(nme) for nme in ('sep_max', 'log_bf', 'dist_post', 'p_single', 'p_any', 'p_i', 'ncat', 'match_flag')]
+		t2 = time.perf_counter()
+		res.plan.close()
+		rec = dict(e2e_ms=(t2 - t0) * 1e3, upload_and_pass_ms=(t1 - t0) * 1e3, download_ms=(t2 - t1) * 1e3, rows=int(m), attempts=int(res.plan.attempts))
+		if best is None or rec['e2e_ms'] < best['e2e_ms']:
+			best = rec
+	return best
 
 
 def table_check(plan, names, cpu_table):
@@ -279,8 +341,8 @@ def main():
 		for col in plan.cols['idx'] + plan.cols['sep']:
 			d2h_bytes += col[:rows_per_step].cpu().numpy().nbytes
 		d2h_s = time.perf_counter() - t0
-		io = dict(h2d_ms=h2d_s * 1e3, h2d_bytes=int(h2d_bytes), d2h_ms=d2h_s * 1e3, d2h_bytes=int(d2h_bytes),
-			note='host arrays -> HBM before the timed region, table -> host after it; never part of `value`')
+		io = dict(h2d_ms=h2d_s * 1e3, h2d_bytes=int(h2d_bytes), h2d_mode=_hip.upload_mode['last'], d2h_ms=d2h_s * 1e3, d2h_bytes=int(d2h_bytes),
+			note='host arrays -> HBM before the timed region (page-locked in place for the copy engine), table -> host after it; never part of `value`')
 	else:
 		step = engine.step
 		read_status = engine.read_status
@@ -370,7 +432,14 @@ def main():
 				pass_bytes=p_bytes, pass_achieved=p_bytes / (ms_per_step * 1e-3) / 1e9, pass_frac=p_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
 				pass_note='SURVEY 8(d): every input column once + 66 B per row, divided by the WHOLE step (all launches and the gaps between them); rank 0'))
 		if io is not None:
+			io.update(end_to_end([primary, secondary], args.radius, args.completeness, device))
+			io['e2e_note'] = ('nway_amd.run_match from host arrays to the table on the host: upload, one pass (with its capacity estimate holding: '
+				'attempts = 1), download of every column; best of 3')
 			out['io'] = io
+			read_gbs, copy_gbs = measured_ceilings(sec_copies, device)
+			out['roofline'].update(read_peak=read_gbs, copy_peak=copy_gbs, frac_of_read_peak=achieved / read_gbs if read_gbs > 0 else None,
+				peaks_note='measured on this box in this run: read_peak = the sweep\'s access pattern with nothing behind the loads (k_read_probe, '
+					'16 B per secondary, three buffers alternating); copy_peak = device-to-device copy of one 80 MB column, bytes read + written')
 		if engine is None and len(plans) == 1 and args.two_pipelines:
 			# supplementary, never `value`: the same steps alternating over TWO independent pipelines
 			# (plan + workspace + table + stream each), so that the latency-bound registration and tail

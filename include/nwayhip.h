@@ -99,7 +99,20 @@ typedef struct nwayhip_match_params {
 	                                      * keep (0 = derived from cap_pairs); see NWAYHIP_ST_REGION_NEED */
 	int64_t f32_roundtrip;               /* 1 = numerics of the script nway.py: separations pass through float32
 	                                      * (FITS 'E' column, fastskymatch.py:328) before being squared in log_bf */
+	/* Tuning: what tests and benchmarks use to force a path on inputs that would not take it.  All 0 =
+	 * the library decides (every caller but those).  Nothing here changes a result, only which kernels
+	 * produce it.  (The library reads NO environment variable unless NWAYHIP_DEV=1 is set: tools/dev.) */
+	int32_t direct_log2;                 /* positions of the sparse front's direct-mapped table, log2 (10..24; > 20: the
+	                                        large-table sweep) */
+	int32_t fold_log2;                   /* large tables: bits of the folded bitmap in LDS, log2 (15..20; < 20 also stages
+	                                        the survivors' coordinates) */
+	int32_t disable;                     /* bit mask NWAYHIP_DISABLE_* */
+	int32_t reserved;
 } nwayhip_match_params;
+#define NWAYHIP_DISABLE_DENSE3 1         /* dense k = 3: the hybrid path instead of the tuple-parallel fused tail */
+#define NWAYHIP_DISABLE_HYBRID 2         /* dense k >= 3: the general path instead of sparse front + general back end */
+#define NWAYHIP_DISABLE_FUSED_CORRECTION 4 /* NWAYHIP_CORRECTION_CLI: k_correct behind the general back end instead of the fused tails */
+#define NWAYHIP_DISABLE_ONE_SWEEP 8      /* sparse k >= 3: one sweep launch per secondary catalogue instead of one for all */
 
 /* Output table, SoA, `capacity` rows allocated by the caller.  Columns follow
  * __init__.py:133-177,100-111,405-418 / SURVEY.md appendix C. */
@@ -141,9 +154,12 @@ int nwayhip_log_bf(int32_t ncat, int64_t n, const double* const* h_sep, const do
 	double* out, void* stream);
 /* bayesdistance.py:207-240  log_bf_elliptical(separations_ra, separations_dec, pos_errors): per-axis
  * separations (arcsec; host arrays of ncat*ncat device pointers, only i<j read) and, per catalogue,
- * the error ellipse as (sigma_x, sigma_y, rho) columns (host arrays of ncat device pointers). */
+ * the error ellipse as (sigma_x, sigma_y, rho) columns (host arrays of ncat device pointers).
+ * f32_offsets = 1: the numerics of the script's main pass (nway.py:346-354), whose offsets are float32
+ * arrays read back from FITS 'E' columns: numpy keeps their length and unit vector in float32. */
 int nwayhip_log_bf_elliptical(int32_t ncat, int64_t n, const double* const* h_sep_ra, const double* const* h_sep_dec,
-	const double* const* h_sigma_x, const double* const* h_sigma_y, const double* const* h_rho, double* out, void* stream);
+	const double* const* h_sigma_x, const double* const* h_sigma_y, const double* const* h_rho, double* out, int32_t f32_offsets,
+	void* stream);
 /* fastskymatch.py:50-74  the two offset columns of dist3d(apos, bpos): longitude and latitude
  * differences (degrees, a minus b) in the offset frame centred on a; -99 inputs give NaN.
  * (The separation column of dist3d is nwayhip_dist.) */
@@ -177,6 +193,29 @@ int32_t nwayhip_plan_link_slots(const nwayhip_plan* plan);
 #define NWAYHIP_PATH_SPARSE 1
 #define NWAYHIP_PATH_HYBRID 2
 int32_t nwayhip_plan_path(const nwayhip_plan* plan);
+/* What exactly the plan launches (tests of the path selection, configuration tables):
+ * h_out[NWAYHIP_DESC_WORDS], indexed by NWAYHIP_DESC_*. */
+#define NWAYHIP_DESC_WORDS 8
+#define NWAYHIP_DESC_PATH 0              /* NWAYHIP_PATH_* */
+#define NWAYHIP_DESC_LINK_SLOTS 1        /* slots per primary and catalogue (0: general path) */
+#define NWAYHIP_DESC_DIRECT_LOG2 2       /* positions of the direct-mapped table, log2 (0: general path) */
+#define NWAYHIP_DESC_SWEEP 3             /* NWAYHIP_SWEEP_* */
+#define NWAYHIP_DESC_TAIL 4              /* NWAYHIP_TAIL_* */
+#define NWAYHIP_DESC_FOLD_LOG2 5         /* large-table sweep: bits of the folded bitmap, log2 (else 0) */
+#define NWAYHIP_DESC_ONE_SWEEP 6         /* 1: all secondary catalogues share one sweep launch */
+#define NWAYHIP_SWEEP_GENERAL 0          /* survivors to regions, k_pairs + k_links behind it */
+#define NWAYHIP_SWEEP_LDS 1              /* sparse front, occupancy bitmap in LDS (tables up to 2^20 positions) */
+#define NWAYHIP_SWEEP_BIG 2              /* sparse front, bitmap in L2, folded copy in LDS */
+#define NWAYHIP_TAIL_GENERAL 0           /* lists + k_rows2 / expansion + k_rows + k_groups */
+#define NWAYHIP_TAIL_SPARSE2 1           /* k_tail2 */
+#define NWAYHIP_TAIL_DENSE2 2            /* k_taild_test + scan + k_taild_rows */
+#define NWAYHIP_TAIL_SPARSEK 3           /* k_tailk<K> */
+#define NWAYHIP_TAIL_DENSE3 4            /* k_taild_test + k_taild3_count + scan + k_taild3_rows */
+#define NWAYHIP_TAIL_HYBRID 5            /* slots -> lists, then the general back end */
+int nwayhip_plan_describe(const nwayhip_plan* plan, int32_t* h_out);
+/* 1 if the plan can run the secondary-split mode below (sparse front with the tails
+ * NWAYHIP_TAIL_SPARSE2 / NWAYHIP_TAIL_DENSE2 / NWAYHIP_TAIL_SPARSEK), else 0 */
+int32_t nwayhip_plan_split_capable(const nwayhip_plan* plan);
 /* Enqueue the whole pipeline on `stream`.  d_status: device int64[NWAYHIP_STATUS_WORDS].
  * The workspace's contents may be arbitrary the first time a plan sees it (the plan clears what
  * it needs); between runs of the same plan on the same workspace they must be left alone (by
@@ -191,7 +230,7 @@ int nwayhip_match_enqueue(nwayhip_plan* plan, const nwayhip_catalogue* h_cats, v
  * secondary) is exported to the rank that owns the primary; one all-to-all of the export buffers
  * (the caller's: torch.distributed / RCCL, nway_amd/distributed.py) delivers them; the back half
  * turns what arrived into the links of the rank's own primaries and runs the fused tail on them.
- * Sparse path only (nwayhip_plan_path() == NWAYHIP_PATH_SPARSE).  The plan is created with n[0] = ALL primaries
+ * Only where nwayhip_plan_split_capable() says so.  The plan is created with n[0] = ALL primaries
  * and n[c] = the rank's slice sizes; capacities and the table are for the rank's own rows.
  *
  * Export buffer: [destination rank][catalogue c - 1][1 + capacity] records of 32 bytes
@@ -250,6 +289,12 @@ int nwayhip_group_stats(int64_t n_rows, int64_t n_groups, const int64_t* group_s
  * weight = log10(ratio); total_inout[r] += weight; bias_out[r] = 10^weight. */
 int nwayhip_bias_lookup(int64_t n_rows, const int32_t* idx, const double* mag, int32_t n_edges, const double* edges,
 	const double* ratio, double* total_inout, double* bias_out, void* stream);
+
+/* Measurement aid (no counterpart in the reference): reads two double columns of n rows once with the
+ * sweep's access pattern -- `blocks` workgroups of 1024 threads on contiguous slices -- and leaves one
+ * partial sum per workgroup in d_out[blocks].  bench.py times it as the machine's ceiling for the
+ * sweep's 16 bytes per secondary (roofline.read_peak). */
+int nwayhip_read_probe(const double* a, const double* b, int64_t n, double* d_out, int32_t blocks, void* stream);
 
 /* fastskymatch.py:94-98 on device-resident columns: out[0..3] = min ra, max ra, max |dec|, #NaN */
 int nwayhip_catalogue_extent(const double* ra, const double* dec, int64_t n, double* d_out4, void* stream);

@@ -134,9 +134,11 @@ class MatchResult(object):
 
 def run_match(match_tables, match_radius, prior_completeness=1.0, prob_ratio_secondary=0.5,
 		radius_filter=True, correction=_hip.CORRECTION_NONE, finalize=True, scheme=None, device=None,
-		logger=None, sphere_cell_factor=0.0, bitmap_bits=0, err_deg=None, link_slots=0, table_slots=0, f32_roundtrip=False, lean=False):
+		logger=None, sphere_cell_factor=0.0, bitmap_bits=0, err_deg=None, link_slots=0, table_slots=0, f32_roundtrip=False, lean=False,
+		tuning=None):
 	"""Upload the catalogues and run the whole HIP pipeline once; returns a MatchResult.
-	lean: see ``_hip.MatchPlan`` (columns nobody reads afterwards are not materialised)."""
+	lean: see ``_hip.MatchPlan`` (columns nobody reads afterwards are not materialised).
+	tuning: see ``_hip.make_params`` (tests force a path with it; never changes a result)."""
 	logger = logger or NullOutputLogger()
 	device = _hip.require_device(device)
 	ncats = len(match_tables)
@@ -155,7 +157,8 @@ def run_match(match_tables, match_radius, prior_completeness=1.0, prob_ratio_sec
 	params = _hip.make_params(ncats, scheme, float(match_radius), err, dens, dens_plus,
 		_prior_table(dens, dens_plus, completeness), prob_ratio_secondary=prob_ratio_secondary,
 		radius_filter=radius_filter, correction=correction, finalize=finalize,
-		sphere_cell_factor=sphere_cell_factor, bitmap_bits=bitmap_bits, link_slots=link_slots, table_slots=table_slots, f32_roundtrip=f32_roundtrip)
+		sphere_cell_factor=sphere_cell_factor, bitmap_bits=bitmap_bits, link_slots=link_slots, table_slots=table_slots, f32_roundtrip=f32_roundtrip,
+		tuning=tuning)
 	cats = [_hip.DeviceCatalogue(ra, dec, numpy.asarray(t['error'], dtype=float), device) for (ra, dec), t in zip(ratables, match_tables)]
 	sizes = [c.n for c in cats]
 	cap_pairs, cap_rows = _estimate_capacities(sizes, [t['area'] * 1.0 for t in match_tables], match_radius, scheme, radius_filter)
@@ -196,7 +199,7 @@ def nway_match(match_tables, match_radius, prior_completeness,
 	prob_ratio_secondary=0.5,
 	min_prob=0., consider_unrelated_associations=True,
 	store_mag_hists=True,
-	logger=default_logger, unrelated_associations='api', device=None, f32_roundtrip=False):
+	logger=default_logger, unrelated_associations='api', device=None, f32_roundtrip=False, tuning=None):
 	"""Same contract as ``nwaylib.nway_match`` (__init__.py:31-120).
 
 	match_tables: list of dicts with name, ra, dec (deg), error (arcsec), area (deg^2),
@@ -210,6 +213,7 @@ def nway_match(match_tables, match_radius, prior_completeness,
 	f32_roundtrip (extension): numerics of the script, whose separations pass through a FITS
 	float32 column before log_bf squares them (fastskymatch.py:328, bayesdistance.py:84); the
 	importable API (the default here) is float64 throughout.
+	tuning (extension): which kernels run (``_hip.make_params``); what the parity tests force paths with.
 	"""
 	import pandas
 	if mag_exclude_radius is None:
@@ -226,7 +230,7 @@ def nway_match(match_tables, match_radius, prior_completeness,
 		raise EmptyResultException('No matches.')  # nothing can create a bucket (fastskymatch.py:131)
 	logger.log('Computing distance-based probabilities ...')
 	res = run_match(match_tables, match_radius, prior_completeness, prob_ratio_secondary,
-		correction=correction, finalize=not has_mags, device=device, logger=logger, f32_roundtrip=f32_roundtrip, lean=not has_mags)
+		correction=correction, finalize=not has_mags, device=device, logger=logger, f32_roundtrip=f32_roundtrip, lean=not has_mags, tuning=tuning)
 	if not res.nrows > 0:
 		raise EmptyResultException('No matches.')
 	logger.log('matching: %6d matches after filtering by search radius' % res.nrows)

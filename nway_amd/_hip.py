@@ -19,6 +19,7 @@ MAXPAIR = 28
 STATUS_WORDS = 32
 ST_ROWS, ST_FLAGS, ST_REGISTRATIONS, ST_TESTS, ST_REGION_NEED, ST_SLOT_NEED = 0, 1, 2, 3, 4, 5
 LINK_SLOTS_CAP = 64
+LINK_SLOTS_MAX_FUSED = 8  # most slots of the one-launch fused tails (sparse.inc: LINK_SLOTS_MAX)
 ST_SURVIVORS, ST_PAIRS, ST_NOTFLAT = 8, 16, 24
 FLAG_PAIR_OVERFLOW, FLAG_ROW_OVERFLOW, FLAG_REG_OVERFLOW, FLAG_SLOT_OVERFLOW, FLAG_LOOKBACK = 1, 2, 4, 8, 16
 PATH_GENERAL, PATH_SPARSE, PATH_HYBRID = 0, 1, 2
@@ -26,6 +27,13 @@ SCHEME_FLAT, SCHEME_SPHERE = 0, 1
 STAGES = 8
 STAGE_NAMES = ['register', 'sweep', 'pairs', 'lists', 'expand', 'rows', 'groups']
 CORRECTION_NONE, CORRECTION_CLI = 0, 1
+DISABLE_DENSE3, DISABLE_HYBRID, DISABLE_FUSED_CORRECTION, DISABLE_ONE_SWEEP = 1, 2, 4, 8
+DESC_WORDS = 8
+DESC_NAMES = ['path', 'link_slots', 'direct_log2', 'sweep', 'tail', 'fold_log2', 'one_sweep', 'reserved']
+SWEEP_GENERAL, SWEEP_LDS, SWEEP_BIG = 0, 1, 2
+SWEEP_NAMES = ['general', 'lds', 'big']
+TAIL_GENERAL, TAIL_SPARSE2, TAIL_DENSE2, TAIL_SPARSEK, TAIL_DENSE3, TAIL_HYBRID = 0, 1, 2, 3, 4, 5
+TAIL_NAMES = ['general', 'sparse2', 'dense2', 'sparsek', 'dense3', 'hybrid']
 
 
 class NwayHipError(RuntimeError):
@@ -44,7 +52,8 @@ class MatchParams(ctypes.Structure):
 		('dens', ctypes.c_double * MAXCAT), ('dens_plus', ctypes.c_double * MAXCAT),
 		('prior_table', ctypes.c_double * (1 << (MAXCAT - 1))),
 		('sphere_cell_factor', ctypes.c_double), ('bitmap_bits', ctypes.c_int64), ('table_slots', ctypes.c_int64),
-		('link_region_min', ctypes.c_int64), ('f32_roundtrip', ctypes.c_int64)]
+		('link_region_min', ctypes.c_int64), ('f32_roundtrip', ctypes.c_int64),
+		('direct_log2', ctypes.c_int32), ('fold_log2', ctypes.c_int32), ('disable', ctypes.c_int32), ('reserved', ctypes.c_int32)]
 
 
 class Table(ctypes.Structure):
@@ -72,7 +81,7 @@ SYMBOLS = {
 	'nwayhip_dist_f32': (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _vp, _vp]),
 	'nwayhip_log_bf': (ctypes.c_int, [_i32, _i64, ctypes.POINTER(_vp), ctypes.POINTER(_vp), _vp, _vp]),
 	'nwayhip_log_bf_elliptical': (ctypes.c_int, [_i32, _i64, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp),
-		ctypes.POINTER(_vp), _vp, _vp]),
+		ctypes.POINTER(_vp), _vp, _i32, _vp]),
 	'nwayhip_offsets': (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
 	'nwayhip_posterior': (ctypes.c_int, [_i32, _vp, _vp, _i64, _vp, _vp]),
 	'nwayhip_plan_create': (ctypes.c_int, [ctypes.POINTER(_vp), ctypes.POINTER(MatchParams), ctypes.POINTER(_i64), _i64, _i64]),
@@ -81,6 +90,8 @@ SYMBOLS = {
 	'nwayhip_plan_table_slots': (ctypes.c_int64, [_vp]),
 	'nwayhip_plan_link_slots': (ctypes.c_int32, [_vp]),
 	'nwayhip_plan_path': (ctypes.c_int32, [_vp]),
+	'nwayhip_plan_describe': (ctypes.c_int, [_vp, ctypes.POINTER(_i32)]),
+	'nwayhip_plan_split_capable': (ctypes.c_int32, [_vp]),
 	'nwayhip_match_enqueue': (ctypes.c_int, [_vp, ctypes.POINTER(Catalogue), _vp, ctypes.c_size_t, ctypes.POINTER(Table), _vp, _vp]),
 	'nwayhip_split_buffer_bytes': (ctypes.c_size_t, [_vp, _i32, _i64]),
 	'nwayhip_split_front_enqueue': (ctypes.c_int, [_vp, ctypes.POINTER(Catalogue), _vp, ctypes.c_size_t, ctypes.POINTER(Split), _vp, _vp]),
@@ -91,6 +102,7 @@ SYMBOLS = {
 	'nwayhip_group_stats': (ctypes.c_int, [_i64, _i64, _vp, _vp, _vp, _dbl, _vp, _vp, _vp, _vp, _vp]),
 	'nwayhip_bias_lookup': (ctypes.c_int, [_i64, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp]),
 	'nwayhip_catalogue_extent': (ctypes.c_int, [_vp, _vp, _i64, _vp, _vp]),
+	'nwayhip_read_probe': (ctypes.c_int, [_vp, _vp, _i64, _vp, _i32, _vp]),
 }
 
 _lib = None
@@ -157,6 +169,53 @@ def require_device(device=None):
 	return t.device(device)
 
 
+UPLOAD_PIN_BYTES = 1 << 20     # columns of at least this size are uploaded from page-locked memory
+UPLOAD_CHUNK_BYTES = 16 << 20  # staging buffers of the fallback path
+upload_mode = {'last': None}   # how the last large column travelled: 'registered' | 'staged' (bench.py reports it)
+
+
+def _upload_large(a, out):
+	"""host array -> device tensor ``out`` (same shape and dtype) at DMA speed.  A pageable source goes
+	through the runtime's own bounce buffers at ~1 GB/s on this stack; page-locking the caller's array
+	in place (hipHostRegister, undone afterwards) lets the copy engine read it directly.  Where the
+	runtime refuses, two pinned staging buffers alternate: the host copies chunk i + 1 into one while
+	the engine drains chunk i from the other."""
+	t = torch()
+	src = t.from_numpy(a)
+	rt = t.cuda.cudart()
+	registered = False
+	try:
+		rc = rt.cudaHostRegister(a.ctypes.data, a.nbytes, 0)
+		registered = int(rc) == 0
+	except Exception:
+		registered = False
+	if registered:
+		try:
+			out.copy_(src, non_blocking=True)
+			t.cuda.current_stream(out.device).synchronize()
+		finally:
+			rt.cudaHostUnregister(a.ctypes.data)
+		upload_mode['last'] = 'registered'
+		return out
+	flat_src, flat_out = src.reshape(-1), out.reshape(-1)
+	per = max(1, UPLOAD_CHUNK_BYTES // a.itemsize)
+	stage = [t.empty(per, dtype=src.dtype, pin_memory=True) for _ in range(2)]
+	done = [None, None]
+	stream = t.cuda.current_stream(out.device)
+	for i, lo in enumerate(range(0, flat_src.shape[0], per)):
+		hi = min(lo + per, flat_src.shape[0])
+		b = i & 1
+		if done[b] is not None:
+			done[b].synchronize()
+		stage[b][:hi - lo].copy_(flat_src[lo:hi])
+		flat_out[lo:hi].copy_(stage[b][:hi - lo], non_blocking=True)
+		done[b] = t.cuda.Event()
+		done[b].record(stream)
+	stream.synchronize()
+	upload_mode['last'] = 'staged'
+	return out
+
+
 def to_device(array, device, dtype=None):
 	"""numpy array or torch tensor -> contiguous device tensor (float64 by default)"""
 	t = torch()
@@ -164,6 +223,10 @@ def to_device(array, device, dtype=None):
 	if isinstance(array, t.Tensor):
 		return array.to(device=device, dtype=dtype).contiguous()
 	a = numpy.ascontiguousarray(numpy.asarray(array), dtype={t.float64: numpy.float64, t.float32: numpy.float32, t.int32: numpy.int32, t.int64: numpy.int64}[dtype])
+	if a.nbytes >= UPLOAD_PIN_BYTES and t.device(device).type == 'cuda':
+		if not a.flags.writeable:
+			a = a.copy()  # (torch.from_numpy wants a writable buffer)
+		return _upload_large(a, t.empty(a.shape, dtype=dtype, device=device))
 	return t.from_numpy(a).to(device)
 
 
@@ -243,7 +306,13 @@ class MatchPlan(object):
 		self.link_slots = int(self.lib.nwayhip_plan_link_slots(handle))
 		self.sparse = self.link_slots > 0   # the sparse front (its overflows send a run to the general path)
 		self.path = int(self.lib.nwayhip_plan_path(handle))
-		self.fused = self.path == PATH_SPARSE
+		self.fused = self.path == PATH_SPARSE  # a fused tail reports exact row counts (run_plan)
+		desc = (ctypes.c_int32 * DESC_WORDS)()
+		check(self.lib.nwayhip_plan_describe(handle, desc))
+		self.description = dict(zip(DESC_NAMES, [int(x) for x in desc]))
+		self.description['sweep'] = SWEEP_NAMES[self.description['sweep']]
+		self.description['tail'] = TAIL_NAMES[self.description['tail']]
+		self.split_capable = bool(self.lib.nwayhip_plan_split_capable(handle))
 		self.attempts = 1  # (run_plan: enqueues it took to settle the capacities)
 		self.lean = bool(lean)
 		skip = set()
@@ -333,8 +402,18 @@ class MatchPlan(object):
 
 
 def make_params(ncat, scheme, radius_arcsec, err_deg, dens, dens_plus, prior_table, prob_ratio_secondary=0.5,
-		radius_filter=True, correction=CORRECTION_NONE, finalize=True, sphere_cell_factor=0.0, bitmap_bits=0, link_slots=0, table_slots=0, f32_roundtrip=False):
+		radius_filter=True, correction=CORRECTION_NONE, finalize=True, sphere_cell_factor=0.0, bitmap_bits=0, link_slots=0, table_slots=0, f32_roundtrip=False,
+		tuning=None):
+	"""tuning: dict with any of direct_log2, fold_log2, disable (DISABLE_* mask), link_slots -- what tests and
+	benchmarks use to force a path (nwayhip.h: nwayhip_match_params); None = the library decides"""
 	p = MatchParams()
+	tuning = dict(tuning or {})
+	link_slots = tuning.pop('link_slots', link_slots)
+	p.direct_log2 = int(tuning.pop('direct_log2', 0))
+	p.fold_log2 = int(tuning.pop('fold_log2', 0))
+	p.disable = int(tuning.pop('disable', 0))
+	if tuning:
+		raise ValueError('unknown tuning keys: %s' % sorted(tuning))
 	p.table_slots = table_slots
 	p.f32_roundtrip = 1 if f32_roundtrip else 0
 	p.link_slots = link_slots

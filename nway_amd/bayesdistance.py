@@ -189,18 +189,24 @@ def convert_from_ellipse(a, b, phi):
 	return sigma_x, sigma_y, rho
 
 
-def log_bf_elliptical(separations_ra, separations_dec, pos_errors):
+def log_bf_elliptical(separations_ra, separations_dec, pos_errors, f32_offsets=None):
 	"""log10 Bayes factor for elliptical errors: pos_errors = list of (sigma_ra, sigma_dec, rho)
 	per catalogue; separations given per axis (n x n nested sequences, entries with i < j read).
 	Each pair's separation is rescaled by the ratio of the circularised to the directional error,
 	then the circular formula applies (bayesdistance.py:207-240).  One device kernel
-	(``nwayhip_log_bf_elliptical``); entries broadcast against each other."""
+	(``nwayhip_log_bf_elliptical``); entries broadcast against each other.
+	f32_offsets: None = like numpy, i.e. float32 arithmetic for the length and the unit vector of the
+	offsets exactly when every offset entry given is a float32 array (what the script hands over from
+	its FITS 'E' columns, nway.py:303-305, 346-354); True / False force it."""
 	n = len(pos_errors)
 	if n < 1 or n > _hip.MAXCAT:
 		raise ValueError('log_bf_elliptical supports 1..%d catalogues' % _hip.MAXCAT)
 	pairs = [(i, j) for i in range(n) for j in range(i + 1, n)]
 	columns = [pos_errors[c][m] for c in range(n) for m in range(3)]
-	columns += [separations_ra[i][j] for i, j in pairs] + [separations_dec[i][j] for i, j in pairs]
+	offs = [separations_ra[i][j] for i, j in pairs] + [separations_dec[i][j] for i, j in pairs]
+	if f32_offsets is None:
+		f32_offsets = len(offs) > 0 and all(getattr(o, 'dtype', None) == numpy.float32 for o in offs)
+	columns += offs
 	(dev, shape, device) = _on_device(columns)
 	t = _hip.torch()
 	nrows = int(dev[0].shape[0])
@@ -213,5 +219,5 @@ def log_bf_elliptical(separations_ra, separations_dec, pos_errors):
 		sra[i * n + j] = dev[3 * n + m].data_ptr()
 		sdec[i * n + j] = dev[3 * n + len(pairs) + m].data_ptr()
 	out = t.empty(nrows, dtype=t.float64, device=device)
-	_hip.check(_hip.load().nwayhip_log_bf_elliptical(n, nrows, sra, sdec, sx, sy, rho, _hip.ptr(out), _hip.current_stream_ptr(device)))
+	_hip.check(_hip.load().nwayhip_log_bf_elliptical(n, nrows, sra, sdec, sx, sy, rho, _hip.ptr(out), 1 if f32_offsets else 0, _hip.current_stream_ptr(device)))
 	return _finish(out, shape)

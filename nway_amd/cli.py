@@ -238,8 +238,8 @@ def main(argv=None):
 				dra, ddec = elliptical.offsets(*(coords(i) + coords(j)))
 				# the script reads the offsets back from FITS 'E' columns (fastskymatch.py:329-331,
 				# nway.py:303-305): what log_bf_elliptical sees are float32 values
-				sep_ra[j][i] = (dra * 60 * 60).astype(numpy.float32).astype(float)
-				sep_dec[j][i] = (ddec * 60 * 60).astype(numpy.float32).astype(float)
+				sep_ra[j][i] = (dra * 60 * 60).astype(numpy.float32)
+				sep_dec[j][i] = (ddec * 60 * 60).astype(numpy.float32)
 				columns.append(('Separation_%s_%s_ra' % (table_names[i], table_names[j]), 'E', sep_ra[j][i]))
 				columns.append(('Separation_%s_%s_dec' % (table_names[i], table_names[j]), 'E', sep_dec[j][i]))
 	sep_max = res.to_host('sep_max')

@@ -77,13 +77,16 @@ class ShardedMatch(object):
 	primary: this rank's shard of the primary catalogue (dict: name, ra, dec, error, area)
 	secondaries: list of this rank's SLICES of the secondary catalogues (same dict layout;
 	  ``error`` may be a scalar)
-	compute: None = the HIP pipeline (needs a GPU); tests pass a callable
-	  ``compute(match_tables, match_radius, prior_completeness, **options) -> dict of columns``
-	  to exercise the sharding logic with gloo on CPU.
+	tuning: development / test knobs of the plan (``_hip.make_params``), normally None
+
+	The exchange logic (``setup``, ``total_rows``, ``gather_table``) only touches the hooks
+	``_exchange_device``, ``_sync``, ``_build_plan``, ``step``, ``local_rows``, ``local_table``;
+	here they are the HIP pipeline and nothing else (no CPU path in this package).  The CPU
+	tests (``tests/test_distributed_gloo.py``) subclass and fill the hooks with the oracle.
 	"""
 
 	def __init__(self, primary, secondaries, match_radius, prior_completeness, device, group=None,
-			prob_ratio_secondary=0.5, compute=None):
+			prob_ratio_secondary=0.5, tuning=None):
 		if isinstance(secondaries, dict):
 			secondaries = [secondaries]
 		self.primary = primary
@@ -93,18 +96,27 @@ class ShardedMatch(object):
 		self.prob_ratio_secondary = prob_ratio_secondary
 		self.device = device
 		self.group = group
-		self.compute = compute
+		self.tuning = tuning
 		self.rank, self.world = world_info(group)
 		self.plan = None
 		self.setup_seconds = None
 		self.setup()
+
+	# -- hooks ---------------------------------------------------------------------------
+	def _exchange_device(self):
+		"""where the exchanged columns live (the GPU: RCCL moves them over xGMI)"""
+		return self.device
+
+	def _sync(self):
+		import torch
+		torch.cuda.synchronize(self.device)
 
 	# -- one-time exchange ---------------------------------------------------------------
 	def setup(self):
 		import torch
 		dist = _dist()
 		t0 = time.perf_counter()
-		dev = self.device if self.compute is None else torch.device('cpu')
+		dev = self._exchange_device()
 		self.full_secondaries = []
 		self.gathered_bytes = 0
 		for sl in self.secondary_slices:
@@ -126,11 +138,9 @@ class ShardedMatch(object):
 		else:
 			self.primary_sizes = [int(n0.item())]
 		self.primary_offset = int(sum(self.primary_sizes[:self.rank]))
-		if self.compute is None:
-			torch.cuda.synchronize(self.device)
+		self._sync()
 		self.setup_seconds = time.perf_counter() - t0
-		if self.compute is None:
-			self._build_plan()
+		self._build_plan()
 
 	def _tables(self):
 		"""match_tables of this rank: own primary shard + complete secondaries"""
@@ -171,7 +181,7 @@ class ShardedMatch(object):
 			[int(sum(self.primary_sizes))] + [int(t['ra'].shape[0]) for t in tables[1:]], [self.primary['area']] + [t['area'] for t in tables[1:]], log)
 		comp = nway_amd._completeness_vector(self.prior_completeness, k)
 		self.params = _hip.make_params(k, scheme, self.match_radius, err, dens, dens_plus, nway_amd._prior_table(dens, dens_plus, comp),
-			prob_ratio_secondary=self.prob_ratio_secondary)
+			prob_ratio_secondary=self.prob_ratio_secondary, tuning=self.tuning)
 		self.cats = [_hip.DeviceCatalogue(self.primary['ra'], self.primary['dec'], numpy.asarray(self.primary['error'], dtype=float), self.device)]
 		for t in tables[1:]:
 			self.cats.append(_hip.DeviceCatalogue(t['ra'], t['dec'], t['error'], self.device))
@@ -185,12 +195,6 @@ class ShardedMatch(object):
 	# -- per batch -----------------------------------------------------------------------
 	def step(self):
 		"""one pass of the hot path over this rank's primary shard (no collective)"""
-		if self.compute is not None:
-			tables = self._tables()
-			tables = [dict(t, ra=numpy.asarray(t['ra']), dec=numpy.asarray(t['dec']),
-				error=(t['error'] if numpy.ndim(t['error']) == 0 else numpy.asarray(t['error']))) for t in tables]
-			self.table = self.compute(tables, self.match_radius, self.prior_completeness, prob_ratio_secondary=self.prob_ratio_secondary)
-			return self.table
 		if not self.empty:
 			self.plan.enqueue(self.cats)
 
@@ -208,8 +212,6 @@ class ShardedMatch(object):
 		return b + per_row * rows
 
 	def local_rows(self):
-		if self.compute is not None:
-			return len(self.table['ncat'])
 		from nway_amd import _hip
 		return int(self.read_status()[_hip.ST_ROWS])
 
@@ -219,16 +221,13 @@ class ShardedMatch(object):
 		n = self.local_rows()
 		if self.world == 1:
 			return n
-		dev = self.device if self.compute is None else torch.device('cpu')
-		t = torch.tensor([n], dtype=torch.int64, device=dev)
+		t = torch.tensor([n], dtype=torch.int64, device=self._exchange_device())
 		_dist().all_reduce(t, group=self.group)
 		return int(t.item())
 
 	def local_table(self):
 		"""this rank's block of the global table as host columns (global primary indices)"""
-		if self.compute is not None:
-			t = dict(self.table)
-		elif self.plan is None:
+		if self.plan is None:
 			names = [self.primary['name']] + [f['name'] for f in self.full_secondaries]
 			from nway_amd import _hip
 			t = dict((nme, numpy.zeros(0, dtype=numpy.int64)) for nme in names + ['ncat', 'match_flag'])
@@ -285,14 +284,16 @@ class SecondarySplitMatch(object):
 
 	primary: this rank's shard of the primary catalogue (the shards are all-gathered once at set-up)
 	secondaries: list of this rank's SLICES of the secondary catalogues (``error`` may be a scalar)
-	compute: None = the HIP pipeline (needs a GPU); the CPU tests pass ``(front, back)`` callables
-	  ``front(primary_all, slices, radius) -> per catalogue (p, s_local) candidate arrays`` and
-	  ``back(primary_own, received, radius, completeness, densities, scheme, prob_ratio_secondary)
-	  -> dict of columns`` to exercise the routing with gloo on CPU.
+	capacity: records per (destination, catalogue) block of the export buffer (None: from the sizes)
+	tuning: development / test knobs of the plan (``_hip.make_params``), normally None
+
+	As in ``ShardedMatch`` the exchange logic only touches the hooks ``_exchange_device``, ``_sync``,
+	``_build_plan``, ``step``, ``local_rows``, ``local_table``: here the HIP pipeline, in the CPU tests
+	(``tests/test_distributed_gloo.py``) a subclass around the oracle.
 	"""
 
 	def __init__(self, primary, secondaries, match_radius, prior_completeness, device, group=None,
-			prob_ratio_secondary=0.5, compute=None, capacity=None):
+			prob_ratio_secondary=0.5, capacity=None, tuning=None):
 		if isinstance(secondaries, dict):
 			secondaries = [secondaries]
 		self.primary = primary
@@ -302,18 +303,26 @@ class SecondarySplitMatch(object):
 		self.prob_ratio_secondary = prob_ratio_secondary
 		self.device = device
 		self.group = group
-		self.compute = compute
 		self.capacity = capacity
+		self.tuning = tuning
 		self.rank, self.world = world_info(group)
 		self.plan = None
 		self.setup()
+
+	# -- hooks ---------------------------------------------------------------------------
+	def _exchange_device(self):
+		return self.device
+
+	def _sync(self):
+		import torch
+		torch.cuda.synchronize(self.device)
 
 	# -- one-time exchange ---------------------------------------------------------------
 	def setup(self):
 		import torch
 		dist = _dist()
 		t0 = time.perf_counter()
-		dev = self.device if self.compute is None else torch.device('cpu')
+		dev = self._exchange_device()
 		f64 = lambda x: torch.as_tensor(numpy.ascontiguousarray(numpy.asarray(x, dtype=float))).to(dev)
 		# every rank needs ALL primaries: coordinates for the registration, errors for nothing but symmetry
 		ra, counts = allgatherv(f64(self.primary['ra']), self.group)
@@ -336,12 +345,15 @@ class SecondarySplitMatch(object):
 				sizes = [int(n.item())]
 			self.sec_global.append(sum(sizes))
 			self.sec_offset.append(sum(sizes[:self.rank]))
-		if self.compute is None:
-			torch.cuda.synchronize(self.device)
+		self._sync()
 		self.setup_seconds = time.perf_counter() - t0
+		# global indices travel as int32 (ExportRec, the idx columns): -1 is the 'absent' marker
+		from nway_amd import _hip
+		for n in [int(self.bounds[-1])] + self.sec_global:
+			if n > _hip.CAPACITY_LIMIT:
+				raise _hip.NwayHipError('a catalogue of %d rows exceeds the int32 index range of the match table' % n)
 		self._decide()
-		if self.compute is None:
-			self._build_plan()
+		self._build_plan()
 
 	def _decide(self):
 		"""densities and cell scheme of the WHOLE catalogues (every rank must use the same)"""
@@ -358,8 +370,7 @@ class SecondarySplitMatch(object):
 		local += [(numpy.asarray(s['ra'], dtype=float), numpy.asarray(s['dec'], dtype=float)) for s in self.secondary_slices]
 		scheme = nway_amd.choose_scheme([t for t in local if len(t[0]) > 0], err) if any(len(t[0]) for t in local) else _hip.SCHEME_FLAT
 		if self.world > 1:
-			dev = self.device if self.compute is None else torch.device('cpu')
-			s = torch.tensor([scheme], dtype=torch.int64, device=dev)
+			s = torch.tensor([scheme], dtype=torch.int64, device=self._exchange_device())
 			_dist().all_reduce(s, op=_dist().ReduceOp.MAX, group=self.group)  # the all-sky scheme wins
 			scheme = int(s.item())
 		self.scheme = scheme
@@ -374,7 +385,7 @@ class SecondarySplitMatch(object):
 		err = self.match_radius / 60. / 60
 		comp = nway_amd._completeness_vector(self.prior_completeness, k)
 		self.params = _hip.make_params(k, self.scheme, self.match_radius, err, self.dens, self.dens_plus,
-			nway_amd._prior_table(self.dens, self.dens_plus, comp), prob_ratio_secondary=self.prob_ratio_secondary)
+			nway_amd._prior_table(self.dens, self.dens_plus, comp), prob_ratio_secondary=self.prob_ratio_secondary, tuning=self.tuning)
 		pa = self.primary_all
 		self.cats = [_hip.DeviceCatalogue(pa['ra'], pa['dec'], pa['error'], self.device)]
 		for s in self.secondary_slices:
@@ -385,12 +396,14 @@ class SecondarySplitMatch(object):
 		_, cap_rows = nway_amd._estimate_capacities([max(n_own, 1)] + self.sec_global, areas, self.match_radius, self.scheme, True)
 		self.bounds_dev = torch.as_tensor(self.bounds).to(self.device)
 		capacity = self.capacity or max(1024, 4 * max(self.primary_sizes) // self.world + 1024)
-		for attempt in range(6):
+		slot_retries = 0
+		for attempt in range(8):
 			self.plan = _hip.MatchPlan(sizes, self.params, 65536, cap_rows, self.device, lean=True)
-			if not self.plan.fused:
-				self.plan.close()
-				raise _hip.NwayHipError('the secondary-split mode needs the sparse path (few chance neighbours per primary); '
-					'shard dense fields by primary rows (ShardedMatch)')
+			if not self.plan.split_capable:
+				# (decided from the plan alone, the same on every rank: nothing has been allocated or exchanged yet)
+				self._drop_plan()
+				raise _hip.NwayHipError('the secondary-split mode needs the sparse path with its one-launch fused tail (few chance '
+					'neighbours per primary); shard dense fields by primary rows (ShardedMatch)')
 			nbytes = self.plan.split_buffer_bytes(self.world, capacity)
 			self.export = torch.zeros(nbytes, dtype=torch.uint8, device=self.device)
 			self.imported = torch.zeros(nbytes, dtype=torch.uint8, device=self.device)
@@ -409,26 +422,42 @@ class SecondarySplitMatch(object):
 			st = self.plan.read_status()
 			flags = int(st[_hip.ST_FLAGS])
 			# every rank must take the same decision: the capacities are part of the exchange's layout
-			f = torch.tensor([flags, int(st[_hip.ST_ROWS])], dtype=torch.int64, device=self.device)
+			f = torch.tensor([flags, int(st[_hip.ST_SLOT_NEED])], dtype=torch.int64, device=self.device)
 			if self.world > 1:
 				allf = [torch.zeros_like(f) for _ in range(self.world)]
 				_dist().all_gather(allf, f, group=self.group)
-				flags_any = 0
+				flags_any, slot_need = 0, 0
 				for x in allf:
 					flags_any |= int(x[0].item())
+					slot_need = max(slot_need, int(x[1].item()))
 			else:
-				flags_any = flags
+				flags_any, slot_need = flags, int(st[_hip.ST_SLOT_NEED])
 			if flags_any == 0:
 				self.status = st
 				return
-			self.plan.close()
+			# the plan and what points into its buffers go before anything is raised or retried
+			self._drop_plan()
+			fatal = flags_any & (_hip.FLAG_LOOKBACK | _hip.FLAG_REG_OVERFLOW)
+			if flags_any & _hip.FLAG_SLOT_OVERFLOW and not fatal and 0 < slot_need <= _hip.LINK_SLOTS_MAX_FUSED and slot_retries < 2:
+				# a clustered primary: once or twice more with the slots the run counted (as run_plan does)
+				slot_retries += 1
+				self.params.link_slots = min(_hip.LINK_SLOTS_MAX_FUSED, slot_need + (slot_need >> 3) + 1)
+			elif flags_any & _hip.FLAG_SLOT_OVERFLOW or fatal:
+				raise _hip.NwayHipError('the secondary-split mode does not fit this input (status flags %d): shard by primary rows' % flags_any)
 			if flags_any & _hip.FLAG_PAIR_OVERFLOW:
 				capacity *= 4
 			if flags_any & _hip.FLAG_ROW_OVERFLOW:
 				cap_rows = min(cap_rows * 2, (1 << 31) - 4096)
-			if flags_any & (_hip.FLAG_SLOT_OVERFLOW | _hip.FLAG_LOOKBACK | _hip.FLAG_REG_OVERFLOW):
-				raise _hip.NwayHipError('the secondary-split mode does not fit this input (status flags %d): shard by primary rows' % flags_any)
 		raise _hip.NwayHipError('secondary-split mode: capacities could not be settled')
+
+	def _drop_plan(self):
+		"""close the plan and forget everything that points into its buffers"""
+		if self.plan is not None:
+			self.plan.close()
+		self.plan = None
+		self.split = None
+		self.export = None
+		self.imported = None
 
 	# -- per step ------------------------------------------------------------------------
 	def _exchange(self):
@@ -446,62 +475,25 @@ class SecondarySplitMatch(object):
 
 	def step(self):
 		"""one pass: register + sweep of the own slices, ONE all-to-all, import + fused tail"""
-		if self.compute is not None:
-			return self._step_cpu()
 		self.plan.split_front(self.cats, self.split)
 		self._exchange()
 		self.plan.split_back(self.cats, self.split)
 
-	def _step_cpu(self):
-		import torch
-		dist = _dist()
-		front, back = self.compute
-		host = lambda t: t.numpy() if hasattr(t, 'numpy') else numpy.asarray(t)
-		pa = dict(self.primary_all, ra=host(self.primary_all['ra']), dec=host(self.primary_all['dec']), error=host(self.primary_all['error']))
-		cands = front(pa, self.secondary_slices, self.match_radius, self.scheme)
-		received = []
-		for c, (p, s_local) in enumerate(cands):
-			sl = self.secondary_slices[c]
-			p = numpy.asarray(p, dtype=numpy.int64)
-			s_local = numpy.asarray(s_local, dtype=numpy.int64)
-			owner = numpy.searchsorted(self.bounds, p, side='right') - 1
-			order = numpy.argsort(owner, kind='stable')
-			rec = numpy.stack([p[order].astype(float), (s_local[order] + self.sec_offset[c]).astype(float), numpy.asarray(sl['ra'], dtype=float)[s_local[order]],
-				numpy.asarray(sl['dec'], dtype=float)[s_local[order]],
-				numpy.broadcast_to(numpy.asarray(sl['error'], dtype=float), numpy.shape(sl['ra']))[s_local[order]]], axis=1) if len(p) else numpy.zeros((0, 5))
-			send_counts = numpy.bincount(owner, minlength=self.world).astype(numpy.int64)
-			if self.world > 1:
-				sc = torch.as_tensor(send_counts)
-				rc = torch.zeros_like(sc)
-				dist.all_to_all_single(rc, sc, group=self.group)
-				out = torch.zeros((int(rc.sum().item()), 5), dtype=torch.float64)
-				dist.all_to_all_single(out, torch.as_tensor(numpy.ascontiguousarray(rec)), [int(x) for x in rc], [int(x) for x in send_counts], group=self.group)
-				got = out.numpy()
-			else:
-				got = rec
-			received.append(got)
-		lo, hi = int(self.bounds[self.rank]), int(self.bounds[self.rank + 1])
-		own = dict(self.primary, ra=numpy.asarray(self.primary['ra'], dtype=float), dec=numpy.asarray(self.primary['dec'], dtype=float))
-		self.table = back(own, lo, received, [s['name'] for s in self.secondary_slices], [s['area'] for s in self.secondary_slices],
-			self.match_radius, self.prior_completeness, (self.dens, self.dens_plus), self.scheme, self.prob_ratio_secondary)
-		return self.table
-
 	def read_status(self):
+		if self.plan is None:
+			raise RuntimeError('SecondarySplitMatch: no plan (set-up failed)')
 		return self.plan.read_status()
 
 	def local_rows(self):
-		if self.compute is not None:
-			return len(self.table['ncat'])
 		from nway_amd import _hip
-		return int(self.plan.read_status()[_hip.ST_ROWS])
+		return int(self.read_status()[_hip.ST_ROWS])
 
 	def total_rows(self):
 		import torch
 		n = self.local_rows()
 		if self.world == 1:
 			return n
-		dev = self.device if self.compute is None else torch.device('cpu')
-		t = torch.tensor([n], dtype=torch.int64, device=dev)
+		t = torch.tensor([n], dtype=torch.int64, device=self._exchange_device())
 		_dist().all_reduce(t, group=self.group)
 		return int(t.item())
 
@@ -517,8 +509,6 @@ class SecondarySplitMatch(object):
 
 	def local_table(self):
 		"""this rank's block of the global table as host columns (global indices throughout)"""
-		if self.compute is not None:
-			return dict(self.table)
 		from nway_amd import _hip
 		st = self.plan.read_status()
 		m = int(st[_hip.ST_ROWS])

@@ -87,7 +87,7 @@ def log_bf_table(k, idx_columns, sep_ra, sep_dec, errors):
 		sra = [[sep_ra[a][b][mask] if a < b else None for b in cats] for a in cats]
 		sdec = [[sep_dec[a][b][mask] if a < b else None for b in cats] for a in cats]
 		errs = [tuple(e[mask] for e in errors[c]) for c in cats]
-		log_bf[mask] = bayesdist.log_bf_elliptical(sra, sdec, errs)
+		log_bf[mask] = bayesdist.log_bf_elliptical(sra, sdec, errs)  # (float32 offsets: numpy's float32 length and unit vector)
 	return log_bf
 
 
@@ -120,7 +120,9 @@ def unrelated_associations(k, idx_columns, ncat, sep_ra, sep_dec, errors, dens, 
 		sdec = [[sep_dec[a][b][sel] if a < b else None for b in cats] for a in cats]
 		errs = [tuple(e[sel] for e in errors[c]) for c in cats]
 		v = numpy.full(nrows, -numpy.inf)
-		v[sel] = numpy.atleast_1d(bayesdist.log_bf_elliptical(sra, sdec, errs)) + numpy.log10(dens[cats[0]] / numpy.prod(dens_plus[cats]))
+		# (the script gathers one row's offsets into a numpy.array next to float64 NaN placeholders, nway.py:402-408:
+		# float32 VALUES, float64 arithmetic)
+		v[sel] = numpy.atleast_1d(bayesdist.log_bf_elliptical(sra, sdec, errs, f32_offsets=False)) + numpy.log10(dens[cats[0]] / numpy.prod(dens_plus[cats]))
 		value[sub] = v
 	missing = everything & ~code
 	for pattern in numpy.unique(missing[cand]):

@@ -5,7 +5,11 @@ TEST INFRASTRUCTURE ONLY (see oracle/nway_oracle.py): the product evaluates thes
 
   log_bf_elliptical   nwaylib/bayesdistance.py:207-240 (with make_invcovmatrix :191-195,
                       vector_normalised :160-163, log_bf :64-86), pinned by
-                      tests/golden/ellmath.npz (values computed with the reference)
+                      tests/golden/ellmath.npz (values computed with the reference); float32
+                      offsets keep numpy's float32 length and unit vector, as in the reference
+  script_flow         the script's whole elliptical branch (nway.py:52-88, 303-305, 327-360,
+                      366-420), pinned by tests/golden/ell_flow.npz (the reference's functions
+                      driven by a transcription of those lines; offsets as below)
   offsets             the two offset columns of dist3d, nwaylib/fastskymatch.py:50-74.
                       PARITY UNPINNED: the reference calls astropy's SkyOffsetFrame, which is
                       absent here; this is the rotation of the sphere that puts the first position
@@ -93,8 +97,10 @@ def unrelated_associations(k, idx_columns, ncat, sep_ra, sep_dec, errors, dens, 
 					continue
 				aug = [c for c in missing if present[j, c]]
 				if len(aug) >= 2:
-					sra = [[numpy.array([sep_ra[a][b][j]]) if a < b else None for b in aug] for a in aug]
-					sdec = [[numpy.array([sep_dec[a][b][j]]) if a < b else None for b in aug] for a in aug]
+					# (nway.py:402-408: one row's offsets gathered into a numpy.array next to float64 NaN placeholders --
+					# float32 VALUES, but float64 arithmetic from here on)
+					sra = [[numpy.array([sep_ra[a][b][j]], dtype=float) if a < b else None for b in aug] for a in aug]
+					sdec = [[numpy.array([sep_dec[a][b][j]], dtype=float) if a < b else None for b in aug] for a in aug]
 					errs = [tuple(numpy.array([e[j]]) for e in errors[c]) for c in aug]
 					logpost = log_bf_elliptical(sra, sdec, errs)[0] + numpy.log10(dens[aug[0]] / numpy.prod(dens_plus[aug]))
 					if logpost > best:
@@ -102,3 +108,57 @@ def unrelated_associations(k, idx_columns, ncat, sep_ra, sep_dec, errors, dens, 
 			if best > 0:
 				out[i] += best
 	return out
+
+
+def convert_from_ellipse(a, b, phi):
+	"""bayesdistance.py:97-112"""
+	a2, b2 = a**2, b**2
+	s, c = numpy.sin(phi), numpy.cos(phi)
+	sigma_x = (a2 * s**2 + b2 * c**2)**0.5
+	sigma_y = (a2 * c**2 + b2 * s**2)**0.5
+	return sigma_x, sigma_y, c * s * (a2 - b2) / (sigma_x * sigma_y)
+
+
+def script_flow(k, idx_columns, ncat, coords, ellipses, dens, dens_plus, completeness):
+	"""What nway.py computes for ``file :major:minor:angle`` inputs between the match table and the
+	group statistics: per-catalogue error triplets on the table's rows (nway.py:52-66), the offset
+	matrices as float32 'E' columns (fastskymatch.py:306-331, nway.py:303-305), the main pass
+	(:327-360) and the correction loop (:366-420).
+	idx_columns: k index columns (-1 = absent); coords[c] = (ra, dec) of catalogue c;
+	ellipses[c] = (major, minor, angle in degrees).  Returns (sep_ra, sep_dec, uncorrected, corrected, prior)."""
+	nrows = len(ncat)
+
+	def merged(c, col):
+		out = numpy.array(numpy.asarray(col, dtype=float)[idx_columns[c]])
+		out[idx_columns[c] < 0] = -99
+		return out
+	errors = []
+	for c in range(k):
+		rho = (merged(c, ellipses[c][2]) - 90) / 180 * numpy.pi
+		errors.append(convert_from_ellipse(merged(c, ellipses[c][0]), merged(c, ellipses[c][1]), rho))
+	sep_ra = [[None] * k for _ in range(k)]
+	sep_dec = [[None] * k for _ in range(k)]
+	for i in range(k):
+		a_ra, a_dec = merged(i, coords[i][0]), merged(i, coords[i][1])
+		for j in range(i):
+			b_ra, b_dec = merged(j, coords[j][0]), merged(j, coords[j][1])
+			lon, lat = offsets(a_ra, a_dec, b_ra, b_dec)
+			sep_ra[j][i] = (numpy.asarray(lon) * 60 * 60).astype(numpy.float32)
+			sep_dec[j][i] = (numpy.asarray(lat) * 60 * 60).astype(numpy.float32)
+	present = [idx >= 0 for idx in idx_columns]
+	log_bf_values = numpy.zeros(nrows) * numpy.nan
+	prior = numpy.zeros(nrows) * numpy.nan
+	for case in range(2**(k - 1)):
+		cats = [0] + [c for c in range(1, k) if (case // 2**(c - 1)) % 2 == 0]
+		mask = numpy.ones(nrows, dtype=bool)
+		for c in range(1, k):
+			mask &= present[c] if c in cats else ~present[c]
+		if not mask.any():
+			continue
+		sra = [[sep_ra[a][b][mask] if a < b else None for b in cats] for a in cats]
+		sdec = [[sep_dec[a][b][mask] if a < b else None for b in cats] for a in cats]
+		errs = [tuple(e[mask] for e in errors[c]) for c in cats]
+		log_bf_values[mask] = log_bf_elliptical(sra, sdec, errs) if len(cats) > 1 else 0.0
+		prior[mask] = dens[0] * numpy.prod(numpy.asarray(completeness)[cats]) / numpy.prod(numpy.asarray(dens_plus)[cats])
+	corrected = unrelated_associations(k, idx_columns, ncat, sep_ra, sep_dec, errors, dens, dens_plus, log_bf_values)
+	return sep_ra, sep_dec, log_bf_values, corrected, prior

@@ -1,0 +1,128 @@
+"""CPU stand-ins for the device halves of nway_amd.distributed, for the gloo tests (no GPU here).
+
+The product classes keep the exchange logic -- sharding, all-gatherv, global indices, the
+candidate all-to-all, rank-order concatenation -- behind a handful of hooks that are the HIP
+pipeline in the package.  These subclasses fill the hooks with the oracle (test infrastructure):
+what is under test is everything in nway_amd.distributed EXCEPT the hooks."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from goldenutil import ROOT
+
+sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+from nway_amd import distributed  # noqa: E402
+
+
+class OracleShardedMatch(distributed.ShardedMatch):
+	"""primary rows sharded, secondaries all-gathered; the per-rank match is the numpy oracle"""
+
+	def _exchange_device(self):
+		return torch.device('cpu')
+
+	def _sync(self):
+		pass
+
+	def _build_plan(self):
+		self.empty = len(self.primary['ra']) == 0
+		self.table = None
+
+	def step(self):
+		import nway_oracle as orc
+		tables = self._tables()
+		tables = [dict(t, ra=np.asarray(t['ra']), dec=np.asarray(t['dec']),
+			error=(t['error'] if np.ndim(t['error']) == 0 else np.asarray(t['error']))) for t in tables]
+		self.table = orc.nway_match(tables, self.match_radius, self.prior_completeness, prob_ratio_secondary=self.prob_ratio_secondary)
+		return self.table
+
+	def local_rows(self):
+		return len(self.table['ncat'])
+
+	def local_table(self):
+		t = dict(self.table)
+		pname = self.primary['name']
+		t[pname] = np.asarray(t[pname]) + self.primary_offset
+		return t
+
+
+def split_front(primary_all, slices, radius, scheme):
+	"""what the device front half exports: per catalogue the candidates (primary, secondary of the slice)"""
+	import nway_oracle as orc
+	out = []
+	for sl in slices:
+		tup = orc.enumerate_tuples([(primary_all['ra'], primary_all['dec']), (sl['ra'], sl['dec'])], radius / 3600., scheme, radius)
+		tup = tup[tup[:, 1] >= 0]
+		out.append((tup[:, 0], tup[:, 1]))
+	return out
+
+
+def split_back(own, p_lo, received, names, areas, radius, completeness, densities, scheme, ratio):
+	"""what the device back half does with the records it received: the match of the own primaries
+	against exactly those secondaries, with the densities and the scheme of the whole catalogues"""
+	import nway_oracle as orc
+	tables = [dict(name=own['name'], ra=own['ra'], dec=own['dec'], error=np.broadcast_to(np.asarray(own['error'], dtype=float), np.shape(own['ra'])), area=own['area'])]
+	gidx = []
+	for c, rec in enumerate(received):
+		g, first = np.unique(rec[:, 1].astype(np.int64), return_index=True)  # ascending global index: the order of the rows is kept
+		gidx.append(g)
+		tables.append(dict(name=names[c], ra=rec[first, 2], dec=rec[first, 3], error=rec[first, 4], area=areas[c]))
+	t = orc.nway_match(tables, radius, completeness, prob_ratio_secondary=ratio, densities=densities, scheme=scheme)
+	t[own['name']] = t[own['name']] + p_lo
+	for c, g in enumerate(gidx):
+		col = t[names[c]]
+		t[names[c]] = np.where(col >= 0, g[np.maximum(col, 0)] if len(g) else col, -1)
+	return t
+
+
+class OracleSecondarySplitMatch(distributed.SecondarySplitMatch):
+	"""the secondary stream split; front half (candidates of the own slices) and back half (table of the
+	own primaries from what arrived) are the oracle, the all-to-all-v between them is gloo"""
+
+	def _exchange_device(self):
+		return torch.device('cpu')
+
+	def _sync(self):
+		pass
+
+	def _build_plan(self):
+		self.table = None
+
+	def step(self):
+		host = lambda t: t.numpy() if hasattr(t, 'numpy') else np.asarray(t)
+		pa = dict(self.primary_all, ra=host(self.primary_all['ra']), dec=host(self.primary_all['dec']), error=host(self.primary_all['error']))
+		cands = split_front(pa, self.secondary_slices, self.match_radius, self.scheme)
+		received = []
+		for c, (p, s_local) in enumerate(cands):
+			sl = self.secondary_slices[c]
+			p = np.asarray(p, dtype=np.int64)
+			s_local = np.asarray(s_local, dtype=np.int64)
+			owner = np.searchsorted(self.bounds, p, side='right') - 1
+			order = np.argsort(owner, kind='stable')
+			rec = np.stack([p[order].astype(float), (s_local[order] + self.sec_offset[c]).astype(float), np.asarray(sl['ra'], dtype=float)[s_local[order]],
+				np.asarray(sl['dec'], dtype=float)[s_local[order]],
+				np.broadcast_to(np.asarray(sl['error'], dtype=float), np.shape(sl['ra']))[s_local[order]]], axis=1) if len(p) else np.zeros((0, 5))
+			send_counts = np.bincount(owner, minlength=self.world).astype(np.int64)
+			if self.world > 1:
+				sc = torch.as_tensor(send_counts)
+				rc = torch.zeros_like(sc)
+				dist.all_to_all_single(rc, sc, group=self.group)
+				out = torch.zeros((int(rc.sum().item()), 5), dtype=torch.float64)
+				dist.all_to_all_single(out, torch.as_tensor(np.ascontiguousarray(rec)), [int(x) for x in rc], [int(x) for x in send_counts], group=self.group)
+				got = out.numpy()
+			else:
+				got = rec
+			received.append(got)
+		lo = int(self.bounds[self.rank])
+		own = dict(self.primary, ra=np.asarray(self.primary['ra'], dtype=float), dec=np.asarray(self.primary['dec'], dtype=float))
+		self.table = split_back(own, lo, received, [s['name'] for s in self.secondary_slices], [s['area'] for s in self.secondary_slices],
+			self.match_radius, self.prior_completeness, (self.dens, self.dens_plus), self.scheme, self.prob_ratio_secondary)
+		return self.table
+
+	def local_rows(self):
+		return len(self.table['ncat'])
+
+	def local_table(self):
+		return dict(self.table)

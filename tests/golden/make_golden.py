@@ -1005,3 +1005,136 @@ def gen_sparse():
 
 if __name__ == '__main__' and ('sparse' in sys.argv[1:] or not sys.argv[1:]):
 	gen_sparse()
+
+
+def gen_ellflow():
+	"""The script's flow for ELLIPTICAL position errors end to end (``file :major:minor:angle``;
+	nway.py:52-88 error columns, :303-305 offset matrices, :327-360 main pass with
+	log_bf_elliptical, :366-420 correction loop with its elliptical branch :402-411, then the
+	posterior / group statistics of :425-586), on three seeded catalogues.
+
+	A transcription of those lines driven with the reference's OWN functions
+	(_create_match_table, convert_from_ellipse, log_bf_elliptical, unnormalised_log_posterior,
+	posterior, _compute_final_probabilities) -- the script itself needs astropy.io.fits.  The two
+	astropy calls inside dist3d (fastskymatch.py:61-67: SkyOffsetFrame(origin=a), transform_to)
+	are replaced by the rotation astropy documents for that frame (oracle/elliptical_oracle.py:
+	offsets; origin to (0, 0), no roll): this pins the BRANCH LOGIC and the numerics around the
+	offsets (float32 'E' columns, numpy's float32 length / unit vector in the main pass, float64 in
+	the correction loop), not astropy -- as allsky.npz does for healpy."""
+	sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(HERE)), 'oracle'))
+	import elliptical_oracle as eo
+	bd = ref.bayesdist
+	rng = np.random.RandomState(31)
+	radius, completeness, ratio = 15.0, 0.9, 0.5
+	half = 0.12
+	area = (2 * half)**2
+	sizes = [400, 3000, 2500]
+	names = ['X', 'O', 'I']
+	cats = []
+	for c, n in enumerate(sizes):
+		ra = np.round(rng.uniform(150.0 - half, 150.0 + half, size=n), 7)
+		dec = np.round(rng.uniform(2.0 - half, 2.0 + half, size=n), 7)
+		if c > 0:
+			m = int(0.7 * sizes[0])
+			ra[:m] = np.round(cats[0]['ra'][:m] + rng.normal(0, 1.2, size=m) / 3600. / np.cos(np.radians(cats[0]['dec'][:m])), 7)
+			dec[:m] = np.round(cats[0]['dec'][:m] + rng.normal(0, 1.2, size=m) / 3600., 7)
+		major = np.round(rng.uniform(0.5, 3.0, size=n), 4)
+		minor = np.round(major * rng.uniform(0.3, 1.0, size=n), 4)
+		angle = np.round(rng.uniform(0, 180, size=n), 3)
+		cats.append(dict(name=names[c], ra=ra, dec=dec, major=major, minor=minor, angle=angle))
+	k = len(cats)
+	tables = [cat(t['name'], t['ra'], t['dec'], np.ones(len(t['ra'])), area) for t in cats]
+	table, resultstable, separations, _ = ref._create_match_table([dict(t, ra=t['ra'].copy(), dec=t['dec'].copy(), error=t['error'].copy()) for t in tables],
+		radius, logger=LOG)
+	idx = resultstable
+	nrows = len(idx)
+
+	def merged(c, col):  # a column of catalogue c in the merged table: -99 where the source is absent (fastskymatch.py:272-279)
+		out = np.array(cats[c][col][idx[:, c]], dtype=float)
+		out[idx[:, c] == -1] = -99
+		return out
+	# nway.py:52-66: per catalogue (sigma_ra, sigma_dec, rho) on the rows of the merged table
+	errors = []
+	for c in range(k):
+		rho = (merged(c, 'angle') - 90) / 180 * np.pi
+		errors.append(bd.convert_from_ellipse(merged(c, 'major'), merged(c, 'minor'), rho))
+	# fastskymatch.py:298-331: offsets in the frame of the LATER catalogue's source, stored as 'E' columns
+	nan = np.ones(nrows) * np.nan
+	sep_ra = [[nan for _ in range(k)] for _ in range(k)]
+	sep_dec = [[nan for _ in range(k)] for _ in range(k)]
+	for i in range(k):
+		a_ra, a_dec = merged(i, 'ra'), merged(i, 'dec')
+		for j in range(i):
+			b_ra, b_dec = merged(j, 'ra'), merged(j, 'dec')
+			col_ra, col_dec = eo.offsets(a_ra, a_dec, b_ra, b_dec)
+			col_ra, col_dec = np.array(col_ra), np.array(col_dec)
+			for col in (col_ra, col_dec):
+				col[a_ra == -99] = np.nan
+				col[b_ra == -99] = np.nan
+			# nway.py:283-305 make_separation_table_matrix: [ti][tj] (ti < tj) = column Separation_{tj}_{ti}_ra
+			sep_ra[j][i] = (col_ra * 60 * 60).astype(np.float32)
+			sep_dec[j][i] = (col_dec * 60 * 60).astype(np.float32)
+	dens, dens_plus = ref._compute_source_densities(tables, logger=LOG)
+	comp = np.array([1.0] + [completeness**(1. / (k - 1)) for _ in range(1, k)])  # nway.py:209
+	# nway.py:327-360
+	log_bf = np.zeros(nrows) * np.nan
+	prior = np.zeros(nrows) * np.nan
+	for case in range(2**(k - 1)):
+		table_mask = np.array([True] + [(case // 2**(ti)) % 2 == 0 for ti in range(k - 1)])
+		mask = True
+		for i in range(1, k):
+			if table_mask[i]:
+				mask = np.logical_and(mask, ~np.isnan(separations[0][i]))
+			else:
+				mask = np.logical_and(mask, np.isnan(separations[0][i]))
+		errors_selected = [(era[mask], edec[mask], ephi[mask]) for (era, edec, ephi), m in zip(errors, table_mask) if m]
+		sra = [[cell[mask] for cell, m in zip(row, table_mask) if m] for row, m in zip(sep_ra, table_mask) if m]
+		sdec = [[cell[mask] for cell, m in zip(row, table_mask) if m] for row, m in zip(sep_dec, table_mask) if m]
+		log_bf[mask] = bd.log_bf_elliptical(sra, sdec, errors_selected)
+		prior[mask] = dens[0] * np.prod(comp[table_mask]) / np.prod(dens_plus[table_mask])
+	assert np.isfinite(prior).all() and np.isfinite(log_bf).all()
+	uncorrected = log_bf.copy()
+	# nway.py:366-420 (elliptical branch :402-411)
+	ncat = table['ncat'].values
+	prim = idx[:, 0]
+	starts = np.flatnonzero(np.r_[True, prim[1:] != prim[:-1]])
+	ends = np.r_[starts[1:], nrows]
+	group_of = np.repeat(np.arange(len(starts)), ends - starts)
+	for i in np.where(ncat <= k - 2)[0]:
+		missing_cats = [c for c, sep in enumerate(separations[0]) if np.isnan(sep[i])]
+		best_logpost = 0
+		g = group_of[i]
+		for j in range(starts[g], ends[g]):
+			if not (ncat[j] > 2):
+				continue
+			augmented_cats = [c for c in missing_cats if not np.isnan(separations[0][c][j])]
+			if len(augmented_cats) >= 2:
+				prior_j = dens[augmented_cats[0]] / np.prod(dens_plus[augmented_cats])
+				sra = [[[sep_ra[c][c2][j]] for c2 in augmented_cats] for c in augmented_cats]
+				sdec = [[[sep_dec[c][c2][j]] for c2 in augmented_cats] for c in augmented_cats]
+				errors_selected = [([errors[c][0][j]], [errors[c][1][j]], [errors[c][2][j]]) for c in augmented_cats]
+				log_bf_j = bd.log_bf_elliptical(np.array(sra), np.array(sdec), np.array(errors_selected))
+				logpost_j = bd.unnormalised_log_posterior(prior_j, log_bf_j, len(augmented_cats))[0]
+				if logpost_j > best_logpost:
+					best_logpost = logpost_j
+		if best_logpost > 0:
+			log_bf[i] += best_logpost
+	assert (log_bf != uncorrected).sum() > 20, 'the correction loop should change some rows of this fixture'
+	# nway.py:425-586 == __init__.py:399-461
+	t2 = table.assign(dist_bayesfactor_uncorrected=uncorrected, dist_bayesfactor=log_bf, dist_post=bd.posterior(prior, log_bf))
+	res = ref._compute_final_probabilities(tables, t2, ratio, prior, log_bf, logger=LOG)
+	out = dict(radius=np.array([radius]), completeness=np.array([completeness]), area=np.array([area]))
+	for c, t in enumerate(cats):
+		for col in ('ra', 'dec', 'major', 'minor', 'angle'):
+			out['in%d_%s' % (c, col)] = t[col]
+	out.update(table_arrays(res, names))
+	for i in range(k):
+		for j in range(i):
+			out['off_ra_%d_%d' % (j, i)] = sep_ra[j][i]
+			out['off_dec_%d_%d' % (j, i)] = sep_dec[j][i]
+	out['changed_rows'] = np.flatnonzero(log_bf != uncorrected)
+	save('ell_flow', **out)
+
+
+if __name__ == '__main__' and ('ellflow' in sys.argv[1:] or not sys.argv[1:]):
+	gen_ellflow()

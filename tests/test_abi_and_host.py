@@ -43,7 +43,8 @@ def test_struct_layout_matches_header(built):
 	from nway_amd import _hip
 	# sizes implied by include/nwayhip.h with natural alignment
 	assert ctypes.sizeof(_hip.Catalogue) == 40
-	assert ctypes.sizeof(_hip.MatchParams) == 6 * 4 + 3 * 8 + 8 * 8 * 2 + 128 * 8 + 5 * 8  # ..., sphere_cell_factor, bitmap_bits, table_slots, link_region_min, f32_roundtrip
+	# ..., sphere_cell_factor, bitmap_bits, table_slots, link_region_min, f32_roundtrip; direct_log2, fold_log2, disable, reserved
+	assert ctypes.sizeof(_hip.MatchParams) == 6 * 4 + 3 * 8 + 8 * 8 * 2 + 128 * 8 + 5 * 8 + 4 * 4
 	assert ctypes.sizeof(_hip.Table) == 8 + 8 * 8 + 28 * 8 + 11 * 8
 
 

@@ -44,7 +44,9 @@ def both_paths(nw, tabs, radius, completeness=0.9, **options):
 	check_properties(t, names, len(tabs[0]['ra']))
 	o = orc_c.nway_match(tabs, radius, completeness, correction='cli' if options.get('correction') else 'api')
 	compare(t, o, names)
-	g, _ = hip_table(nw, tabs, radius, completeness, **dict(options, link_slots=-1))
+	general = dict(options, link_slots=-1)
+	general.pop('tuning', None)
+	g, _ = hip_table(nw, tabs, radius, completeness, **general)
 	assert g['_path'] == 0
 	# the same table; groups of more than 64 rows are summed in another order by the general path's
 	# group kernel (rows.inc: group_wave), hence the last bits of their probabilities
@@ -69,28 +71,26 @@ def test_dense_two_way_field_stays_on_the_sparse_front():
 
 
 @pytest.mark.parametrize('fold', [19, 20])
-def test_dense_two_way_field_with_a_table_beyond_the_lds(monkeypatch, fold):
+def test_dense_two_way_field_with_a_table_beyond_the_lds(fold):
 	import nway_amd as nw
 	from nway_amd import _hip
-	monkeypatch.setenv('NWAYHIP_DIRECT_LOG2', '21')
-	monkeypatch.setenv('NWAYHIP_FOLD_LOG2', str(fold))
 	rng = np.random.default_rng(12)
 	tabs = patch_tables(rng, [3001, 200001], 0.21, [rng.uniform(0.3, 1.5, size=3001), 0.1], centre=(0.1, -0.05))  # cells of both signs, odd sizes
-	t = both_paths(nw, tabs, 5.0)
+	t = both_paths(nw, tabs, 5.0, tuning=dict(direct_log2=21, fold_log2=fold))
 	assert t['_path'] == _hip.PATH_SPARSE and t['_link_slots'] > 8
+	assert t['_desc']['sweep'] == 'big' and t['_desc']['fold_log2'] == fold and t['_desc']['tail'] == 'dense2'
 
 
 @pytest.mark.parametrize('fold', [19, 20])
-def test_all_sky_field_with_a_table_beyond_the_lds(monkeypatch, fold):
+def test_all_sky_field_with_a_table_beyond_the_lds(fold):
 	import bench
 	import nway_amd as nw
 	from nway_amd import _hip
-	monkeypatch.setenv('NWAYHIP_DIRECT_LOG2', '22')
-	monkeypatch.setenv('NWAYHIP_FOLD_LOG2', str(fold))
 	prim, sec = bench.make_workload(20000, 1500001, 5)
 	sec = dict(sec, error=0.1 * np.ones(len(sec['ra'])))
-	t = both_paths(nw, [prim, sec], 20.0)
+	t = both_paths(nw, [prim, sec], 20.0, tuning=dict(direct_log2=22, fold_log2=fold))
 	assert t['_path'] == _hip.PATH_SPARSE
+	assert t['_desc']['sweep'] == 'big' and t['_desc']['direct_log2'] == 22 and t['_desc']['tail'] == 'sparse2'
 
 
 def test_dense_three_way_field_tuple_parallel_tail():
@@ -171,10 +171,8 @@ def test_four_way_with_the_scripts_correction_fused_and_on_the_general_back_end(
 		tabs.append(dict(b, name=name, error=sig * np.ones(n)))
 	t = both_paths(nw, tabs, 10.0, correction=_hip.CORRECTION_CLI)
 	assert t['_path'] == _hip.PATH_SPARSE   # k_tailk<4, true>: one lane per primary corrects its rows
-	monkeypatch.setenv('NWAYHIP_FUSED_CORRECTION', '0')
-	t = both_paths(nw, tabs, 10.0, correction=_hip.CORRECTION_CLI)
+	t = both_paths(nw, tabs, 10.0, correction=_hip.CORRECTION_CLI, tuning=dict(disable=_hip.DISABLE_FUSED_CORRECTION))
 	assert t['_path'] == _hip.PATH_HYBRID   # the same with k_correct behind the general back end
-	monkeypatch.delenv('NWAYHIP_FUSED_CORRECTION')
 	# a dense 4-way field with the correction: hybrid
 	dense = patch_tables(rng, [1500, 15000, 20000, 12000], 0.21, [1.0, 0.1, 0.5, 0.3])
 	t = both_paths(nw, dense, 10.0, correction=_hip.CORRECTION_CLI)

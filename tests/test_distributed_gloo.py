@@ -1,7 +1,8 @@
 """world_size-2 tests of the sharding logic with the gloo backend on CPU.
 
 The HIP kernels cannot run here, so the per-rank compute is the CPU oracle (test
-infrastructure); what is under test is nway_amd.distributed: row sharding of the
+infrastructure, plugged into the engines' hooks by the subclasses of tests/cpu_engines.py --
+nway_amd.distributed itself has no CPU path); what is under test is nway_amd.distributed: row sharding of the
 primaries, all-gatherv of uneven secondary slices, global indices and the rank-order
 concatenation reproducing the unsharded table exactly."""
 import os
@@ -34,11 +35,6 @@ def make_catalogues():
 	return patch(401, 'A', 3.), patch(6001, 'B', 1.), patch(5000, 'C', 2.)
 
 
-def oracle_compute(tables, radius, completeness, **kw):
-	import nway_oracle as orc
-	return orc.nway_match(tables, radius, completeness, prob_ratio_secondary=kw.get('prob_ratio_secondary', 0.5))
-
-
 def worker(rank, world, port, outfile):
 	os.environ['MASTER_ADDR'] = '127.0.0.1'
 	os.environ['MASTER_PORT'] = str(port)
@@ -58,8 +54,9 @@ def worker(rank, world, port, outfile):
 		cb = [0, 1200, len(C['ra'])] if world == 2 else distributed.shard_bounds(len(C['ra']), world)
 		def rows(t, lo, hi):
 			return dict(t, ra=t['ra'][lo:hi], dec=t['dec'][lo:hi], error=t['error'][lo:hi])
-		sm = distributed.ShardedMatch(rows(A, pb[rank], pb[rank + 1]), [rows(B, bb[rank], bb[rank + 1]), rows(C, cb[rank], cb[rank + 1])],
-			20., 0.85, device=torch.device('cpu'), compute=oracle_compute)
+		from cpu_engines import OracleShardedMatch
+		sm = OracleShardedMatch(rows(A, pb[rank], pb[rank + 1]), [rows(B, bb[rank], bb[rank + 1]), rows(C, cb[rank], cb[rank + 1])],
+			20., 0.85, device=torch.device('cpu'))
 		assert sm.primary_offset == pb[rank]
 		assert [len(f['ra']) for f in sm.full_secondaries] == [len(B['ra']), len(C['ra'])]
 		sm.step()
@@ -93,36 +90,7 @@ def test_shard_bounds():
 	assert list(distributed.shard_bounds(2, 4)) == [0, 1, 2, 2, 2]
 
 
-# ---- secondary-split mode (one job over several ranks): CPU stand-ins for the two device halves ----
-
-def split_front(primary_all, slices, radius, scheme):
-	"""what the device front half exports: per catalogue the candidates (primary, secondary of the slice)"""
-	import nway_oracle as orc
-	out = []
-	for sl in slices:
-		tup = orc.enumerate_tuples([(primary_all['ra'], primary_all['dec']), (sl['ra'], sl['dec'])], radius / 3600., scheme, radius)
-		tup = tup[tup[:, 1] >= 0]
-		out.append((tup[:, 0], tup[:, 1]))
-	return out
-
-
-def split_back(own, p_lo, received, names, areas, radius, completeness, densities, scheme, ratio):
-	"""what the device back half does with the records it received: the match of the own primaries
-	against exactly those secondaries, with the densities and the scheme of the whole catalogues"""
-	import nway_oracle as orc
-	tables = [dict(name=own['name'], ra=own['ra'], dec=own['dec'], error=np.broadcast_to(np.asarray(own['error'], dtype=float), np.shape(own['ra'])), area=own['area'])]
-	gidx = []
-	for c, rec in enumerate(received):
-		g, first = np.unique(rec[:, 1].astype(np.int64), return_index=True)  # ascending global index: the order of the rows is kept
-		gidx.append(g)
-		tables.append(dict(name=names[c], ra=rec[first, 2], dec=rec[first, 3], error=rec[first, 4], area=areas[c]))
-	t = orc.nway_match(tables, radius, completeness, prob_ratio_secondary=ratio, densities=densities, scheme=scheme)
-	t[own['name']] = t[own['name']] + p_lo
-	for c, g in enumerate(gidx):
-		col = t[names[c]]
-		t[names[c]] = np.where(col >= 0, g[np.maximum(col, 0)] if len(g) else col, -1)
-	return t
-
+# ---- secondary-split mode (one job over several ranks): CPU stand-ins for the two device halves in tests/cpu_engines.py ----
 
 def split_worker(rank, world, port, outfile, k):
 	os.environ['MASTER_ADDR'] = '127.0.0.1'
@@ -137,8 +105,8 @@ def split_worker(rank, world, port, outfile, k):
 		def rows(t, lo, hi):
 			return dict(t, ra=t['ra'][lo:hi], dec=t['dec'][lo:hi], error=t['error'][lo:hi])
 		secs = [rows(B, bb[rank], bb[rank + 1]), rows(C, cb[rank], cb[rank + 1])][:k - 1]
-		sm = distributed.SecondarySplitMatch(rows(A, pb[rank], pb[rank + 1]), secs, 20., 0.85, device=torch.device('cpu'),
-			compute=(split_front, split_back))
+		from cpu_engines import OracleSecondarySplitMatch
+		sm = OracleSecondarySplitMatch(rows(A, pb[rank], pb[rank + 1]), secs, 20., 0.85, device=torch.device('cpu'))
 		assert list(sm.bounds) == pb and sm.primary_offset == pb[rank]
 		assert sm.sec_global == [len(B['ra']), len(C['ra'])][:k - 1] and sm.sec_offset == [bb[rank], cb[rank]][:k - 1]
 		sm.step()

@@ -246,3 +246,78 @@ def test_offsets_known_answers():
 	# an offset of one arcsecond due east at declination 60: lon' = atan2(cos 60 sin(dra), ...) -> dra cos(dec) to first order
 	lon, lat = elliptical.offsets(15.0, 60.0, 15.0 + 1 / 3600., 60.0)
 	assert abs(lon * 3600 + 0.5) < 1e-6 and abs(lat * 3600) < 1e-5
+
+
+def _ellflow_inputs(g):
+	k = 3
+	cats = [dict((col, g['in%d_%s' % (c, col)]) for col in ('ra', 'dec', 'major', 'minor', 'angle')) for c in range(k)]
+	return k, cats, float(g['radius'][0]), float(g['completeness'][0]), float(g['area'][0])
+
+
+def test_elliptical_oracle_reproduces_the_scripts_flow():
+	"""oracle/elliptical_oracle.py: script_flow against tests/golden/ell_flow.npz -- the script's
+	``:major:minor:angle`` branch (nway.py:52-88, 303-305, 327-360, 366-420) evaluated with the
+	REFERENCE's functions (make_golden.py: gen_ellflow; dist3d's two astropy calls replaced by the
+	documented rotation: pins the branch logic and its float32 / float64 numerics, not astropy)"""
+	import os
+	import sys
+	sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'oracle'))
+	import elliptical_oracle as eo
+	g = golden('ell_flow')
+	k, cats, radius, completeness, area = _ellflow_inputs(g)
+	idx = [g['idx'][:, c].astype(np.int64) for c in range(k)]
+	sizes = [len(c['ra']) for c in cats]
+	dens = np.array([n / area * (4 * np.pi * (180 / np.pi)**2) for n in sizes])
+	dens_plus = np.array([(n + 1) / area * (4 * np.pi * (180 / np.pi)**2) for n in sizes])
+	dens_plus[0] = dens[0]
+	comp = np.array([1.0] + [completeness**(1. / (k - 1))] * (k - 1))
+	sep_ra, sep_dec, unc, cor, prior = eo.script_flow(k, idx, g['ncat'].astype(np.int64), [(c['ra'], c['dec']) for c in cats],
+		[(c['major'], c['minor'], c['angle']) for c in cats], dens, dens_plus, comp)
+	for i in range(k):
+		for j in range(i):
+			np.testing.assert_array_equal(sep_ra[j][i], g['off_ra_%d_%d' % (j, i)])
+			np.testing.assert_array_equal(sep_dec[j][i], g['off_dec_%d_%d' % (j, i)])
+	np.testing.assert_allclose(unc, g['dist_bayesfactor_uncorrected'], rtol=1e-12, atol=1e-12)
+	np.testing.assert_allclose(cor, g['dist_bayesfactor'], rtol=1e-12, atol=1e-12)
+	np.testing.assert_array_equal(np.flatnonzero(cor != unc), g['changed_rows'])
+	assert len(g['changed_rows']) > 20
+
+
+@pytest.mark.gpu
+def test_cli_elliptical_flow_golden(tmp_path, monkeypatch):
+	"""nway.py with ``:major:minor:angle`` error columns on three catalogues, FITS in, FITS out, against
+	tests/golden/ell_flow.npz (see the oracle test above for what the fixture pins): rows, offsets,
+	uncorrected and corrected Bayes factors, posteriors, group statistics, match_flag"""
+	from nway_amd import _fits, cli
+	g = golden('ell_flow')
+	k, cats, radius, completeness, area = _ellflow_inputs(g)
+	names = ['X', 'O', 'I']
+	monkeypatch.chdir(tmp_path)
+	argv = ['--radius', '%g' % radius, '--prior-completeness', '%g' % completeness]
+	for name, c in zip(names, cats):
+		n = len(c['ra'])
+		_fits.write_table('%s.fits' % name, [('ID', 'J', np.arange(n)), ('RA', 'D', c['ra']), ('DEC', 'D', c['dec']),
+			('major', 'D', c['major']), ('minor', 'D', c['minor']), ('angle', 'D', c['angle'])], name, table_header={'SKYAREA': area})
+		argv += ['%s.fits' % name, ':major:minor:angle']
+	assert cli.main(argv + ['--out', 'out.fits']) == 0
+	d = _fits.read_table('out.fits').data
+	m = len(g['ncat'])
+	assert len(d) == m
+	for c, name in enumerate(names):
+		ids = np.asarray(d[name + '_ID'], dtype=np.int64)
+		np.testing.assert_array_equal(np.where(ids == -99, -1, ids), g['idx'][:, c])
+	np.testing.assert_array_equal(np.asarray(d['ncat'], dtype=np.int64), g['ncat'])
+	f32 = lambda x: np.asarray(x, dtype=np.float32)
+	for i in range(k):
+		for j in range(i):
+			for axis, key in (('ra', 'off_ra_%d_%d'), ('dec', 'off_dec_%d_%d')):
+				got = np.asarray(d['Separation_%s_%s_%s' % (names[i], names[j], axis)], dtype=float)
+				# (float32 columns of offsets that the device and numpy evaluate with different libm: one float32 ulp, or 1e-6 arcsec near zero)
+				np.testing.assert_allclose(got, g[key % (j, i)].astype(float), rtol=2.4e-7, atol=1e-6, equal_nan=True, err_msg=key % (j, i))
+	# the table's floating columns are float32 ('E'): the contract's 1e-6 relative, on top of the float32 rounding
+	for col, key in (('dist_bayesfactor', 'dist_bayesfactor_uncorrected'), ('dist_bayesfactor_corrected', 'dist_bayesfactor'), ('dist_post', 'dist_post'),
+			('p_single', 'p_single'), ('p_any', 'prob_has_match'), ('p_i', 'prob_this_match')):
+		np.testing.assert_allclose(np.asarray(d[col], dtype=float), f32(g[key]).astype(float), rtol=2e-6, atol=1e-9, err_msg=col)
+	np.testing.assert_array_equal(np.asarray(d['match_flag'], dtype=np.int64), g['match_flag'])
+	changed = np.flatnonzero(np.asarray(d['dist_bayesfactor_corrected']) != np.asarray(d['dist_bayesfactor']))
+	assert len(changed) > 20 and set(changed) <= set(g['changed_rows'])

@@ -62,6 +62,7 @@ def hip_table(nw, tables, radius, completeness, **options):
 	t['_sparse'] = res.plan.sparse
 	t['_path'] = res.plan.path
 	t['_link_slots'] = res.plan.link_slots
+	t['_desc'] = dict(res.plan.description)
 	res.plan.close()
 	return t, status
 

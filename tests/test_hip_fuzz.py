@@ -17,11 +17,11 @@ pytestmark = pytest.mark.gpu
 FLOATS = ('Separation_max', 'dist_bayesfactor_uncorrected', 'dist_bayesfactor', 'dist_post', 'p_single', 'prob_has_match', 'prob_this_match')
 
 
-def compare(nw, tabs, radius, completeness, correction, f32=False):
+def compare(nw, tabs, radius, completeness, correction, f32=False, tuning=None):
 	names = [t['name'] for t in tabs]
 	want = orc.nway_match(tabs, radius, completeness, correction=correction, literal_groups=True, f32_roundtrip=f32)
 	got = nw.nway_match(tabs, radius, completeness, logger=nw.NullOutputLogger(),
-		unrelated_associations='cli' if correction == 'cli' else 'api', f32_roundtrip=f32)
+		unrelated_associations='cli' if correction == 'cli' else 'api', f32_roundtrip=f32, tuning=tuning)
 	assert len(got) == len(want['ncat']), (len(got), len(want['ncat']))
 	for n in names:
 		np.testing.assert_array_equal(got[n].values, want[n])
@@ -107,22 +107,21 @@ def test_random_configurations(seed):
 
 @pytest.mark.parametrize('seed', range(40, 64))
 @pytest.mark.parametrize('forced', ['large-table', 'dense-tails'])
-def test_random_configurations_on_forced_paths(monkeypatch, seed, forced):
+def test_random_configurations_on_forced_paths(seed, forced):
 	"""the same on paths these small inputs would not take by themselves: a direct-mapped table beyond
 	the LDS of a sweep workgroup (k_sweep_big), 24 slots per primary (candidate- / tuple-parallel
 	tails, the general back end fed from the slots)"""
 	import nway_amd as nw
-	monkeypatch.setenv('NWAYHIP_DIRECT_LOG2', '21')
+	tuning = dict(direct_log2=21)
 	if forced == 'dense-tails':
-		monkeypatch.setenv('NWAYHIP_LINK_SLOTS', '24')
-		monkeypatch.setenv('NWAYHIP_FOLD_LOG2', '19')
+		tuning.update(link_slots=24, fold_log2=19)
 	rng = np.random.default_rng(1000 + seed)
 	k = int(rng.integers(2, 6))
 	tabs, radius = (flat_case if seed % 2 == 0 else sphere_case)(rng, k)
 	if seed % 2 == 1 and k > 4:
 		tabs = tabs[:4]
 	comp = float(rng.choice([1.0, 0.9, 0.5]))
-	rows = compare(nw, tabs, radius, comp, 'cli' if seed % 3 == 0 else 'api', f32=(seed % 5 == 0))
+	rows = compare(nw, tabs, radius, comp, 'cli' if seed % 3 == 0 else 'api', f32=(seed % 5 == 0), tuning=tuning)
 	assert rows >= len(tabs[0]['ra'])
 
 

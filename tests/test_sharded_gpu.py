@@ -1,0 +1,133 @@
+"""The primary-row sharding on the device (what BASELINE configs[3] / [4] name): two ranks (gloo,
+sharing the one GPU of the test box) each own a contiguous range of primaries, all-gather their
+slices of the secondary catalogues and run the HIP pipeline on their shard; the rank-order
+concatenation must equal the single-GPU table of the same catalogues AND the oracle's.
+Also: bench.py itself under torch.distributed.run with two ranks, both scaling modes."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from goldenutil import ROOT, RTOL, ATOL, cat
+
+sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+
+pytestmark = pytest.mark.gpu
+
+
+def free_port():
+	s = socket.socket()
+	s.bind(('127.0.0.1', 0))
+	port = s.getsockname()[1]
+	s.close()
+	return port
+
+
+def catalogues(k, flat):
+	rng = np.random.RandomState(91)
+	n0, n1, n2 = 20000, 300000, 200000
+	if flat:
+		sky = lambda n: (rng.uniform(200.0, 220.0, n), rng.uniform(-15.0, 15.0, n))
+		area = 20.0 * 30.0
+	else:
+		sky = lambda n: (rng.uniform(0, 360, n), np.degrees(np.arcsin(rng.uniform(-1, 1, n))))
+		area = 41252.96
+	a = cat('A', *sky(n0), rng.uniform(0.5, 2, n0), area)
+	b = cat('B', *sky(n1), rng.uniform(0.2, 0.4, n1), area)
+	c = cat('C', *sky(n2), 0.5 * np.ones(n2), area)
+	for t, m in ((b, 14000), (c, 9000)):
+		t['ra'][:m] = a['ra'][:m] + rng.normal(0, 1, m) / 3600.
+		t['dec'][:m] = np.clip(a['dec'][:m] + rng.normal(0, 1, m) / 3600., -90, 90)
+	return [a, b, c][:k]
+
+
+def worker(rank, world, port, outfile, k, flat, cut):
+	os.environ['MASTER_ADDR'] = '127.0.0.1'
+	os.environ['MASTER_PORT'] = str(port)
+	os.environ['HSA_ENABLE_IPC_MODE_LEGACY'] = '0'
+	dist.init_process_group('gloo', rank=rank, world_size=world)
+	try:
+		sys.path.insert(0, ROOT)
+		from nway_amd import distributed
+		tabs = catalogues(k, flat)
+		dev = torch.device('cuda', 0)
+		torch.cuda.set_device(dev)
+		n0 = len(tabs[0]['ra'])
+		pb = [0, int(cut * n0), n0]  # cut = 1.0: the second rank owns no primary at all
+		def rows(t, lo, hi):
+			return dict(t, ra=t['ra'][lo:hi], dec=t['dec'][lo:hi], error=t['error'][lo:hi])
+		secs = []
+		for c in range(1, k):
+			n = len(tabs[c]['ra'])
+			sc = [0, int(0.41 * n), n]  # uneven slices of the secondaries as well
+			secs.append(rows(tabs[c], sc[rank], sc[rank + 1]))
+		sm = distributed.ShardedMatch(rows(tabs[0], pb[rank], pb[rank + 1]), secs, 10., 0.9, device=dev)
+		assert sm.primary_offset == pb[rank]
+		assert [int(f['ra'].shape[0]) for f in sm.full_secondaries] == [len(t['ra']) for t in tabs[1:]]
+		for _ in range(3):  # (repeated steps recycle the scratch copies)
+			sm.step()
+		total = sm.total_rows()
+		table = sm.gather_table(dst=0)
+		if rank == 0:
+			np.savez(outfile, total=total, **table)
+	finally:
+		dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('k,flat,cut', [(2, False, 0.7), (3, False, 0.35), (2, True, 0.5), (3, True, 0.6), (2, False, 1.0)])
+def test_primary_shards_on_device(tmp_path, k, flat, cut):
+	import nway_amd as nw
+	import nway_oracle_c as orc_c
+	outfile = str(tmp_path / 'sharded.npz')
+	mp.spawn(worker, args=(2, free_port(), outfile, k, flat, cut), nprocs=2, join=True)
+	got = np.load(outfile)
+	tabs = catalogues(k, flat)
+	names = [t['name'] for t in tabs]
+	# the single-GPU table of the library: identical, bit for bit
+	want = nw.nway_match(tabs, 10., 0.9, logger=nw.NullOutputLogger())
+	assert int(got['total']) == len(want) > len(tabs[0]['ra'])
+	for key in want.columns:
+		np.testing.assert_array_equal(got[key], want[key].values, err_msg=key)
+	# and the oracle's
+	o = orc_c.nway_match(tabs, 10., 0.9)
+	for n in names:
+		np.testing.assert_array_equal(got[n], o[n])
+	np.testing.assert_array_equal(got['ncat'], o['ncat'])
+	np.testing.assert_array_equal(got['match_flag'], o['match_flag'])
+	for c in ('Separation_max', 'dist_bayesfactor', 'dist_post', 'p_single', 'prob_has_match', 'prob_this_match'):
+		np.testing.assert_allclose(got[c], o[c], rtol=RTOL, atol=ATOL, err_msg=c)
+
+
+@pytest.mark.parametrize('scaling', ['weak', 'strong'])
+def test_bench_under_torchrun_two_ranks(tmp_path, scaling):
+	"""bench.py as the driver launches it for N > 1 (one process per rank, torch.distributed.run), here
+	with two gloo ranks on the one GPU and a reduced workload: the JSON line of rank 0"""
+	env = dict(os.environ, NWAY_BENCH_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+	cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+		'--master-port', str(free_port()), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '5', '--warmup', '2', '--prewarm', '3',
+		'--n-primary', '20000', '--n-secondary', '2000000', '--scaling', scaling]
+	res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, timeout=600, env=env, cwd=ROOT)
+	assert res.returncode == 0, res.stderr[-3000:]
+	line = [l for l in res.stdout.splitlines() if l.startswith('{')][-1]
+	out = json.loads(line)
+	assert out['n_gpus'] == 2 and out['steps'] == 5 and out['scaling'] == scaling
+	assert out['metric'] == 'candidate Bayes-factor evals/s' and out['value'] > 0 and out['ms_per_step'] > 0
+	rows = out['config']['rows_per_step']
+	if scaling == 'weak':
+		# every rank owns 20 000 primaries (80 % of them with a counterpart): its rows, twice
+		assert 2 * 20000 * 1.7 < rows < 2 * 20000 * 1.9
+	else:
+		assert 20000 * 1.7 < rows < 20000 * 1.9
+	assert out['roofline']['frac'] > 0 and out['roofline']['pass_frac'] > 0
+	(tmp_path / ('bench_x2_%s.json' % scaling)).write_text(line)
+	keep = os.path.join(ROOT, 'gpurun_out')
+	if os.path.isdir(keep):
+		with open(os.path.join(keep, 'bench_x2_%s.json' % scaling), 'w') as f:
+			f.write(line + '\n')

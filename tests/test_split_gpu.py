@@ -45,7 +45,7 @@ def catalogues(k, flat):
 	return [a, b, c][:k]
 
 
-def worker(rank, world, port, outfile, k, flat, capacity=None):
+def worker(rank, world, port, outfile, k, flat, capacity=None, tuning=None):
 	os.environ['MASTER_ADDR'] = '127.0.0.1'
 	os.environ['MASTER_PORT'] = str(port)
 	os.environ['HSA_ENABLE_IPC_MODE_LEGACY'] = '0'
@@ -64,7 +64,7 @@ def worker(rank, world, port, outfile, k, flat, capacity=None):
 			n = len(tabs[c]['ra'])
 			cut = [0, int(0.37 * n), n]
 			secs.append(rows(tabs[c], cut[rank], cut[rank + 1]))
-		sm = distributed.SecondarySplitMatch(rows(tabs[0], pb[rank], pb[rank + 1]), secs, 10., 0.9, device=dev, capacity=capacity)
+		sm = distributed.SecondarySplitMatch(rows(tabs[0], pb[rank], pb[rank + 1]), secs, 10., 0.9, device=dev, capacity=capacity, tuning=tuning)
 		if capacity is not None:
 			assert sm.capacity > capacity  # the export blocks overflowed and were enlarged, on every rank alike
 		for _ in range(3):  # (repeated steps: the export headers and the scratch copies are recycled)
@@ -105,14 +105,12 @@ def test_secondary_split_grows_its_export_blocks(tmp_path):
 
 
 @pytest.mark.parametrize('k,flat', [(2, False), (3, True)])
-def test_secondary_split_with_a_table_beyond_the_lds(tmp_path, monkeypatch, k, flat):
+def test_secondary_split_with_a_table_beyond_the_lds(tmp_path, k, flat):
 	"""the large-table sweep (sweepbig.inc) in split mode: survivors flushed by their waves, routed
 	and exported by the workgroup at the end"""
 	import nway_amd as nw
 	outfile = str(tmp_path / 'split.npz')
-	monkeypatch.setenv('NWAYHIP_DIRECT_LOG2', '21')
-	mp.spawn(worker, args=(2, free_port(), outfile, k, flat), nprocs=2, join=True)
-	monkeypatch.delenv('NWAYHIP_DIRECT_LOG2')
+	mp.spawn(worker, args=(2, free_port(), outfile, k, flat, None, dict(direct_log2=21)), nprocs=2, join=True)
 	got = np.load(outfile)
 	tabs = catalogues(k, flat)
 	want = nw.nway_match(tabs, 10., 0.9, logger=nw.NullOutputLogger())

@@ -14,7 +14,9 @@ sys.path.insert(0, ROOT)
 dev = torch.device('cuda', 0)
 BLOCKS, STAMPS = 1024, 8
 buf = torch.zeros(3 * BLOCKS * STAMPS, dtype=torch.int64, device=dev)
-os.environ['NWAYHIP_DBG_PTR'] = str(buf.data_ptr())
+os.environ["NWAYHIP_DEV"] = "1"  # the library reads its development switches only then (plan.inc: env_int)
+os.environ["NWAYHIP_DBG_PTR"] = str(buf.data_ptr())
+os.environ.setdefault("NWAYHIP_LIBRARY", os.path.join(ROOT, "tools", "dev", "bin", "lib_dev.so"))  # a -DNWAYHIP_DEVBUILD build carries the stamps
 import bench  # noqa: E402
 import nway_amd  # noqa: E402
 from nway_amd import _hip  # noqa: E402

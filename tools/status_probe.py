@@ -74,6 +74,7 @@ dev = torch.device('cuda', 0)
 phases = None
 if os.environ.get('NWAYHIP_PHASES'):  # development: wall-clock stamps of the last fused kernel's workgroups (common.inc: dbg_stamp)
 	phases = torch.zeros(3 * 1024 * 8, dtype=torch.int64, device=dev)
+	os.environ['NWAYHIP_DEV'] = '1'
 	os.environ['NWAYHIP_DBG_PTR'] = str(phases.data_ptr())
 log = nway_amd.NullOutputLogger()
 err = radius / 3600.
