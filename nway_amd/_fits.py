@@ -175,13 +175,16 @@ def _decode_table(raw, header):
 			# scaled integers: unsigned columns are stored with TZERO = 2^(bits - 1) (the FITS convention,
 			# what astropy writes for IDs); anything else becomes float64 like astropy's
 			unsigned = scale == 1 and zero == 2 ** (8 * base.itemsize - 1)
-			base = numpy.dtype('u%d' % base.itemsize) if unsigned else numpy.dtype('f8')
+			signed_byte = scale == 1 and base == numpy.dtype('u1') and zero == -128  # the other standard convention: 'B' + TZERO = -128 is int8
+			base = numpy.dtype('u%d' % base.itemsize) if unsigned else (numpy.dtype('i1') if signed_byte else numpy.dtype('f8'))
 		native.append((fld[0], base) + tuple(fld[2:]))
 	out = numpy.empty(nrows, dtype=numpy.dtype(native))
 	formats = []
 	for (fld, tform, scale, zero), nat in zip(kept, native):
 		col = table[fld[0]]
-		if numpy.dtype(nat[1]).kind == 'u' and numpy.dtype(fld[1]).kind == 'i':
+		if numpy.dtype(nat[1]) == numpy.dtype('i1') and numpy.dtype(fld[1]) == numpy.dtype('u1'):
+			out[fld[0]] = (col.astype(numpy.int16) - 128).astype(numpy.int8)
+		elif numpy.dtype(nat[1]).kind == 'u' and numpy.dtype(fld[1]).kind == 'i':
 			if numpy.dtype(nat[1]).itemsize == 8:
 				out[fld[0]] = col.astype(numpy.int64).view(numpy.uint64) ^ numpy.uint64(1 << 63)  # + 2^63 mod 2^64
 			else:
@@ -206,6 +209,7 @@ def _card(key, value, comment=''):
 		v = "'%-8s'" % s
 		if len(v) > 70:
 			v = v[:69] + "'"
+		v = '%-20s' % v  # fixed format: the value field ends in column 30 (what astropy and STIL write)
 	card = '%-8s= %s' % (key[:8], v)
 	if comment:
 		card += ' / ' + comment
@@ -255,6 +259,8 @@ def write_table(filename, columns, extname, primary_header=None, table_header=No
 		a = numpy.asarray(arr)
 		if a.dtype.kind == 'u' and letter in 'IJK' and a.dtype.itemsize == numpy.dtype(_TFORM[letter][0]).itemsize:
 			tzero[name] = 2 ** (8 * a.dtype.itemsize - 1)  # the FITS convention for unsigned integers
+		if a.dtype == numpy.int8 and letter == 'B':
+			tzero[name] = -128  # and for signed bytes
 	be = numpy.dtype(fields)
 	data = numpy.zeros(nrows, dtype=be)
 	for (name, tform, arr), fld in zip(columns, fields):
@@ -265,6 +271,8 @@ def write_table(filename, columns, extname, primary_header=None, table_header=No
 			arr = numpy.char.encode(arr, 'ascii')
 		if name in tzero:
 			arr = (arr.astype(numpy.int64) - tzero[name]) if arr.dtype.itemsize < 8 else (arr ^ numpy.uint64(1 << 63)).view(numpy.int64)
+			if tzero[name] == -128:
+				arr = arr.astype(numpy.uint8)
 		with numpy.errstate(invalid='ignore', over='ignore'):
 			data[name] = arr.astype(be[name].base if be[name].subdtype else be[name], copy=False)
 

@@ -17,14 +17,18 @@ from . import _hip
 def dist(apos, bpos):
 	"""Angular separation in degrees between positions (ra, dec) in degrees; scalars or
 	equal-length arrays, as fastskymatch.py:26-47.  The dtype follows the inputs like numpy's
-	(SURVEY A.8): four float32 arrays are evaluated in float32 and give float32 (k_dist_f32),
-	anything else in float64."""
+	(SURVEY A.8): where numpy's promotion of the four arguments gives float32 -- float32 arrays,
+	possibly next to Python scalars, which are weak -- the separation is evaluated in float32 and
+	returned as float32 (k_dist_f32); anything else in float64."""
 	(a_ra, a_dec), (b_ra, b_dec) = apos, bpos
 	device = _hip.require_device()
 	t = _hip.torch()
-	given = [numpy.asarray(x) for x in (a_ra, a_dec, b_ra, b_dec)]
-	if all(g.dtype == numpy.float32 and g.ndim > 0 for g in given):
-		arrs = numpy.broadcast_arrays(*given)
+	args = (a_ra, a_dec, b_ra, b_dec)
+	# numpy.result_type treats Python scalars as weak (NEP 50); 0-d arrays and numpy scalars carry their own dtype
+	promoted = numpy.result_type(*[x if isinstance(x, (int, float)) and not isinstance(x, bool) else numpy.asarray(x) for x in args])
+	given = [numpy.asarray(x) for x in args]
+	if promoted == numpy.float32 and any(g.ndim > 0 for g in given):
+		arrs = numpy.broadcast_arrays(*[g.astype(numpy.float32) for g in given])
 		shape = arrs[0].shape
 		dev = [_hip.to_device(numpy.ascontiguousarray(a).reshape(-1), device, t.float32) for a in arrs]
 		n = int(dev[0].shape[0])

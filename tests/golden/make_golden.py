@@ -1138,3 +1138,40 @@ def gen_ellflow():
 
 if __name__ == '__main__' and ('ellflow' in sys.argv[1:] or not sys.argv[1:]):
 	gen_ellflow()
+
+
+def gen_fitshdr():
+	"""header cards (80-character records, text) of the BINTABLE extensions of two of the reference's own data
+	files, written by a foreign FITS writer (STIL / TOPCAT): what tests/test_fits_columns.py holds the own
+	writer's cards against, byte for byte"""
+	import json
+	out = {}
+	for key, path in (('COSMOS_XMM', 'doc/COSMOS_XMM.fits'), ('randomcatX', 'tests/elltest/randomcatX.fits')):
+		raw = open(os.path.join(REFERENCE, path), 'rb').read()
+		hdus, at = [], 0
+		while at < len(raw) and len(hdus) < 2:
+			cards = []
+			while True:
+				card = raw[at:at + 80].decode('ascii')
+				at += 80
+				cards.append(card)
+				if card.startswith('END'):
+					break
+			at = (at + 2879) // 2880 * 2880
+			hdr = dict((c[:8].strip(), c[10:30].strip()) for c in cards if c[8:10] == '= ')
+			nbytes = abs(int(hdr.get('BITPIX', 8))) // 8
+			naxis = int(hdr.get('NAXIS', 0))
+			for i in range(1, naxis + 1):
+				nbytes *= int(hdr['NAXIS%d' % i])
+			if naxis == 0:
+				nbytes = 0
+			at += (nbytes + 2879) // 2880 * 2880
+			hdus.append(cards)
+		out[key] = hdus[1]
+	with open(os.path.join(HERE, 'foreign_fits_headers.json'), 'w') as f:
+		json.dump(out, f, indent=1)
+	print('foreign_fits_headers.json', dict((k, len(v)) for k, v in out.items()))
+
+
+if __name__ == '__main__' and ('fitshdr' in sys.argv[1:] or not sys.argv[1:]):
+	gen_fitshdr()

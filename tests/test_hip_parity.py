@@ -82,8 +82,18 @@ def test_dist_keeps_float32_like_numpy(nw):
 	want = orc.dist((a_ra, a_dec), (b_ra, b_dec))
 	assert got.dtype == np.float32 and want.dtype == np.float32
 	np.testing.assert_allclose(got, want, rtol=2e-4, atol=3e-5)
+	# (tolerance: one ulp of the float32 longitudes in radians, 4.8e-7 rad = 2.7e-5 deg, is what a last-bit difference
+	# of sinf / cosf / atan2f becomes in the difference of two nearby longitudes)
 	# float64 in, float64 out, as before
 	assert nw.match.dist((a_ra.astype(float), a_dec.astype(float)), (b_ra.astype(float), b_dec.astype(float))).dtype == np.float64
+	# numpy's promotion decides (NEP 50): Python scalars are weak and leave float32 arrays float32 ...
+	got = nw.match.dist((a_ra, a_dec), (10.0, 20.0))
+	want = orc.dist((a_ra, a_dec), (10.0, 20.0))
+	assert got.dtype == np.float32 and want.dtype == np.float32 and got.shape == want.shape
+	np.testing.assert_allclose(got, want, rtol=2e-4, atol=3e-5)
+	# ... a float64 numpy scalar or array is not
+	assert nw.match.dist((a_ra, a_dec), (np.float64(10.0), 20.0)).dtype == np.float64
+	assert nw.match.dist((a_ra, a_dec), (b_ra.astype(float), b_dec)).dtype == np.float64
 
 
 def test_ell2_golden(nw):

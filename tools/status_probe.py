@@ -4,6 +4,8 @@
 
 c3s: 2-way uniform sky (bench workload)      c3d: 2-way dense 6 deg^2 patch (flat cells)
 c4s: 3-way uniform sky, 1e5 x 1e6 x 1e6     c4d: 3-way dense 8 deg^2 patch     c6d: 4-way dense (hybrid path)
+c1x / c2x: BASELINE configs[0] / [1] on the stand-ins (C1', C2'): the reference's real COSMOS_XMM (1 797 sources)
+x seeded OPT (560 536) [x IRAC (345 512)] in 2 deg^2, radius 20 arcsec
 """
 import os
 import sys
@@ -20,7 +22,7 @@ args = sys.argv[1:]
 config = args.pop(0) if args and not args[0].isdigit() else 'c3s'
 n0 = int(args[0]) if len(args) > 0 else 100000
 n1 = int(args[1]) if len(args) > 1 else (10000000 if config.startswith('c3') else 1000000)
-radius = float(args[2]) if len(args) > 2 else (5.0 if config.startswith('c3') else 10.0)
+radius = float(args[2]) if len(args) > 2 else (5.0 if config.startswith('c3') else (20.0 if config in ('c1x', 'c2x') else 10.0))
 force_slots = int(os.environ.get('PROBE_LINK_SLOTS', '0'))
 rng = np.random.default_rng(3)
 
@@ -66,6 +68,10 @@ elif config == 'c6d':  # 4-way dense: 1e5 x 5e5 x 5e5 x 5e5 in 8 deg^2 (the hybr
 	prim = patch_catalogue('P', n0, 1.42, psig)
 	tables = [prim, patch_catalogue('A', n1 // 2, 1.42, 0.1, prim, 0.8, psig), patch_catalogue('B', n1 // 2, 1.42, 0.5, prim, 0.6, psig),
 		patch_catalogue('C', n1 // 2, 1.42, 0.3, prim, 0.5, psig)]
+elif config in ('c1x', 'c2x'):
+	sys.path.insert(0, os.path.join(ROOT, 'tests'))
+	from goldenutil import xmm_tables
+	tables = list(xmm_tables())[:2 if config == 'c1x' else 3]
 else:
 	raise SystemExit('unknown config ' + config)
 
@@ -88,6 +94,7 @@ sizes = [c.n for c in cats]
 cap_pairs, cap_rows = nway_amd._estimate_capacities(sizes, [t['area'] for t in tables], radius, scheme, True)
 plan, st = _hip.run_plan(sizes, params, cats, cap_pairs, cap_rows, dev, lean=True)
 print('path:', ('general', 'sparse', 'hybrid')[plan.path], 'link_slots', plan.link_slots)
+print('plan:', ' '.join('%s=%s' % kv for kv in sorted(plan.description.items())), 'attempts=%d' % plan.attempts)
 print(config, 'scheme', scheme, 'status', [int(x) for x in st[:4]], 'surv', [int(x) for x in st[8:8 + k - 1]],
 	'pairs', [int(x) for x in st[16:16 + k - 1]], 'notflat', [int(x) for x in st[24:24 + k]])
 import time
