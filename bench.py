@@ -233,6 +233,7 @@ def main():
 	ap.add_argument('--profile-stages', action='store_true', help='also time every stage (adds event records to the region)')
 	ap.add_argument('--prewarm', type=int, default=200, help='untimed steps before the W warm-up steps: the first ~10 ms after an idle period run at lower clocks (20 steps right after start-up: 82 us each, after 200: 78.5)')
 	ap.add_argument('--two-pipelines', type=int, default=1, help='also time the steps alternating over two independent pipelines (reported beside, never as, `value`); 0 = skip')
+	ap.add_argument('--fused-front', action='store_true', help='development: the registration inside the sweep launch (NWAYHIP_ENABLE_FUSED_FRONT)')
 	ap.add_argument('--streams', type=int, default=int(os.environ.get('NWAY_BENCH_STREAMS', '1')),
 		help='independent pipelines (own workspace, own output table, own HIP stream) the steps alternate over')
 	args = ap.parse_args()
@@ -255,6 +256,8 @@ def main():
 			dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank % ngpu))
 		else:
 			dist.init_process_group(backend)
+	# development: --fused-front runs the registration inside the sweep launch (nwayhip.h: NWAYHIP_ENABLE_FUSED_FRONT)
+	tuning = dict(enable=_hip.ENABLE_FUSED_FRONT) if args.fused_front else None
 	if args.gpus != world:
 		if rank == 0:
 			sys.stderr.write('note: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE\n' % (args.gpus, world))
@@ -273,7 +276,7 @@ def main():
 		n_sec_local = args.n_secondary // world + (args.n_secondary % world if rank == world - 1 else 0)
 		primary, secondary = make_workload(args.n_primary, n_sec_local, args.seed + 1000 * rank)
 		from nway_amd import distributed
-		engine = distributed.ShardedMatch(primary, [secondary], args.radius, args.completeness, device)
+		engine = distributed.ShardedMatch(primary, [secondary], args.radius, args.completeness, device, tuning=tuning)
 	elif strong:
 		# strong scaling: ONE job of n_primary x n_secondary.  Every rank generates the same
 		# catalogues (same seed) and keeps its slice of the secondaries and its shard of the primaries
@@ -283,7 +286,7 @@ def main():
 		pb = distributed.shard_bounds(args.n_primary, world)
 		sec_slice = dict(secondary, ra=secondary['ra'][sb[rank]:sb[rank + 1]], dec=secondary['dec'][sb[rank]:sb[rank + 1]])
 		prim_shard = dict(primary, ra=primary['ra'][pb[rank]:pb[rank + 1]], dec=primary['dec'][pb[rank]:pb[rank + 1]], error=primary['error'][pb[rank]:pb[rank + 1]])
-		engine = distributed.SecondarySplitMatch(prim_shard, [sec_slice], args.radius, args.completeness, device)
+		engine = distributed.SecondarySplitMatch(prim_shard, [sec_slice], args.radius, args.completeness, device, tuning=tuning)
 	else:
 		primary, secondary = make_workload(args.n_primary, args.n_secondary, args.seed)
 
@@ -294,7 +297,7 @@ def main():
 		scheme = nway_amd.choose_scheme([(t['ra'], t['dec']) for t in tables], err)
 		dens, dens_plus = nway_amd._compute_source_densities(tables, log)
 		comp = nway_amd._completeness_vector(args.completeness, 2)
-		params = _hip.make_params(2, scheme, args.radius, err, dens, dens_plus, nway_amd._prior_table(dens, dens_plus, comp))
+		params = _hip.make_params(2, scheme, args.radius, err, dens, dens_plus, nway_amd._prior_table(dens, dens_plus, comp), tuning=tuning)
 		torch.cuda.synchronize(device)
 		t0 = time.perf_counter()
 		cats = [_hip.DeviceCatalogue(t['ra'], t['dec'], np.asarray(t['error'], dtype=float), device) for t in tables]
@@ -444,8 +447,10 @@ def main():
 			# supplementary, never `value`: the same steps alternating over TWO independent pipelines
 			# (plan + workspace + table + stream each), so that the latency-bound registration and tail
 			# of one pass run beside those of the other (the sweeps cannot share a CU: 156 KB of LDS each)
-			second = _hip.MatchPlan(sizes, params, plan.cap_pairs, plan.cap_rows, device, lean=True)
-			pair, lanes = [plan, second], [torch.cuda.Stream(device=device) for _ in range(2)]
+			params2 = _hip.make_params(2, scheme, args.radius, err, dens, dens_plus, nway_amd._prior_table(dens, dens_plus, comp))
+			second = _hip.MatchPlan(sizes, params2, plan.cap_pairs, plan.cap_rows, device, lean=True)
+			first = plan if not args.fused_front else _hip.MatchPlan(sizes, params2, plan.cap_pairs, plan.cap_rows, device, lean=True)
+			pair, lanes = [first, second], [torch.cuda.Stream(device=device) for _ in range(2)]
 
 			def two(n):
 				for j in range(n):
@@ -460,8 +465,10 @@ def main():
 			assert int(second.read_status()[_hip.ST_FLAGS]) == 0 and int(second.read_status()[_hip.ST_ROWS]) == rows_per_step
 			out['two_pipelines'] = dict(streams=2, ms_per_step=ms2, value=rows_per_step / (ms2 * 1e-3),
 				pass_frac=p_bytes / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS,
-				note='supplementary: the same passes, two in flight on separate HIP streams; `value` above is one pass at a time')
+				note='supplementary: the same passes, two in flight on separate HIP streams ; `value` above is one pass at a time')
 			second.close()
+			if first is not plan:
+				first.close()
 		if args.profile_stages:
 			out['stages_ms'] = dict((name, ms[i] / max(launches[i], 1) * (launches[i] / float(args.steps)))
 				for i, name in enumerate(_hip.STAGE_NAMES))

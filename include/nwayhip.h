@@ -57,6 +57,8 @@ extern "C" {
 #define NWAYHIP_FLAG_REG_OVERFLOW 4      /* registration table too small */
 #define NWAYHIP_FLAG_SLOT_OVERFLOW 8     /* a primary has more links than link_slots: repeat with more (NWAYHIP_ST_SLOT_NEED) or link_slots = -1 */
 #define NWAYHIP_FLAG_LOOKBACK 16         /* the single-pass scan timed out: repeat with link_slots = -1 */
+#define NWAYHIP_FLAG_BARRIER 32          /* the sweep launch that also registers the primaries did not get the GPU to itself
+                                            (its workgroups wait for each other): repeat without NWAYHIP_ENABLE_FUSED_FRONT */
 
 typedef struct nwayhip_catalogue {
 	const double* ra;                    /* degrees */
@@ -107,12 +109,17 @@ typedef struct nwayhip_match_params {
 	int32_t fold_log2;                   /* large tables: bits of the folded bitmap in LDS, log2 (15..20; < 20 also stages
 	                                        the survivors' coordinates) */
 	int32_t disable;                     /* bit mask NWAYHIP_DISABLE_* */
-	int32_t reserved;
+	int32_t enable;                      /* bit mask NWAYHIP_ENABLE_*: variants that are off by default */
 } nwayhip_match_params;
 #define NWAYHIP_DISABLE_DENSE3 1         /* dense k = 3: the hybrid path instead of the tuple-parallel fused tail */
 #define NWAYHIP_DISABLE_HYBRID 2         /* dense k >= 3: the general path instead of sparse front + general back end */
 #define NWAYHIP_DISABLE_FUSED_CORRECTION 4 /* NWAYHIP_CORRECTION_CLI: k_correct behind the general back end instead of the fused tails */
 #define NWAYHIP_DISABLE_ONE_SWEEP 8      /* sparse k >= 3: one sweep launch per secondary catalogue instead of one for all */
+#define NWAYHIP_ENABLE_FUSED_FRONT 1     /* the registration of the primaries INSIDE the sweep launch (front.inc: k_sweep<.., FUSED>;
+                                            sparse front with the bitmap in LDS): one launch and one kernel boundary fewer,
+                                            the first tiles hashed across a grid barrier.  Measured no faster than the two
+                                            launches and in need of the whole GPU (NWAYHIP_FLAG_BARRIER):
+                                            off unless asked for */
 
 /* Output table, SoA, `capacity` rows allocated by the caller.  Columns follow
  * __init__.py:133-177,100-111,405-418 / SURVEY.md appendix C. */
@@ -203,6 +210,7 @@ int32_t nwayhip_plan_path(const nwayhip_plan* plan);
 #define NWAYHIP_DESC_TAIL 4              /* NWAYHIP_TAIL_* */
 #define NWAYHIP_DESC_FOLD_LOG2 5         /* large-table sweep: bits of the folded bitmap, log2 (else 0) */
 #define NWAYHIP_DESC_ONE_SWEEP 6         /* 1: all secondary catalogues share one sweep launch */
+#define NWAYHIP_DESC_FUSED_FRONT 7       /* 1: that launch also registers the primaries */
 #define NWAYHIP_SWEEP_GENERAL 0          /* survivors to regions, k_pairs + k_links behind it */
 #define NWAYHIP_SWEEP_LDS 1              /* sparse front, occupancy bitmap in LDS (tables up to 2^20 positions) */
 #define NWAYHIP_SWEEP_BIG 2              /* sparse front, bitmap in L2, folded copy in LDS */

@@ -21,15 +21,16 @@ ST_ROWS, ST_FLAGS, ST_REGISTRATIONS, ST_TESTS, ST_REGION_NEED, ST_SLOT_NEED = 0,
 LINK_SLOTS_CAP = 64
 LINK_SLOTS_MAX_FUSED = 8  # most slots of the one-launch fused tails (sparse.inc: LINK_SLOTS_MAX)
 ST_SURVIVORS, ST_PAIRS, ST_NOTFLAT = 8, 16, 24
-FLAG_PAIR_OVERFLOW, FLAG_ROW_OVERFLOW, FLAG_REG_OVERFLOW, FLAG_SLOT_OVERFLOW, FLAG_LOOKBACK = 1, 2, 4, 8, 16
+FLAG_PAIR_OVERFLOW, FLAG_ROW_OVERFLOW, FLAG_REG_OVERFLOW, FLAG_SLOT_OVERFLOW, FLAG_LOOKBACK, FLAG_BARRIER = 1, 2, 4, 8, 16, 32
 PATH_GENERAL, PATH_SPARSE, PATH_HYBRID = 0, 1, 2
 SCHEME_FLAT, SCHEME_SPHERE = 0, 1
 STAGES = 8
 STAGE_NAMES = ['register', 'sweep', 'pairs', 'lists', 'expand', 'rows', 'groups']
 CORRECTION_NONE, CORRECTION_CLI = 0, 1
 DISABLE_DENSE3, DISABLE_HYBRID, DISABLE_FUSED_CORRECTION, DISABLE_ONE_SWEEP = 1, 2, 4, 8
+ENABLE_FUSED_FRONT = 1
 DESC_WORDS = 8
-DESC_NAMES = ['path', 'link_slots', 'direct_log2', 'sweep', 'tail', 'fold_log2', 'one_sweep', 'reserved']
+DESC_NAMES = ['path', 'link_slots', 'direct_log2', 'sweep', 'tail', 'fold_log2', 'one_sweep', 'fused_front']
 SWEEP_GENERAL, SWEEP_LDS, SWEEP_BIG = 0, 1, 2
 SWEEP_NAMES = ['general', 'lds', 'big']
 TAIL_GENERAL, TAIL_SPARSE2, TAIL_DENSE2, TAIL_SPARSEK, TAIL_DENSE3, TAIL_HYBRID = 0, 1, 2, 3, 4, 5
@@ -53,7 +54,7 @@ class MatchParams(ctypes.Structure):
 		('prior_table', ctypes.c_double * (1 << (MAXCAT - 1))),
 		('sphere_cell_factor', ctypes.c_double), ('bitmap_bits', ctypes.c_int64), ('table_slots', ctypes.c_int64),
 		('link_region_min', ctypes.c_int64), ('f32_roundtrip', ctypes.c_int64),
-		('direct_log2', ctypes.c_int32), ('fold_log2', ctypes.c_int32), ('disable', ctypes.c_int32), ('reserved', ctypes.c_int32)]
+		('direct_log2', ctypes.c_int32), ('fold_log2', ctypes.c_int32), ('disable', ctypes.c_int32), ('enable', ctypes.c_int32)]
 
 
 class Table(ctypes.Structure):
@@ -404,7 +405,7 @@ class MatchPlan(object):
 def make_params(ncat, scheme, radius_arcsec, err_deg, dens, dens_plus, prior_table, prob_ratio_secondary=0.5,
 		radius_filter=True, correction=CORRECTION_NONE, finalize=True, sphere_cell_factor=0.0, bitmap_bits=0, link_slots=0, table_slots=0, f32_roundtrip=False,
 		tuning=None):
-	"""tuning: dict with any of direct_log2, fold_log2, disable (DISABLE_* mask), link_slots -- what tests and
+	"""tuning: dict with any of direct_log2, fold_log2, disable (DISABLE_* mask), enable (ENABLE_* mask), link_slots -- what tests and
 	benchmarks use to force a path (nwayhip.h: nwayhip_match_params); None = the library decides"""
 	p = MatchParams()
 	tuning = dict(tuning or {})
@@ -412,6 +413,7 @@ def make_params(ncat, scheme, radius_arcsec, err_deg, dens, dens_plus, prior_tab
 	p.direct_log2 = int(tuning.pop('direct_log2', 0))
 	p.fold_log2 = int(tuning.pop('fold_log2', 0))
 	p.disable = int(tuning.pop('disable', 0))
+	p.enable = int(tuning.pop('enable', 0))
 	if tuning:
 		raise ValueError('unknown tuning keys: %s' % sorted(tuning))
 	p.table_slots = table_slots
@@ -468,6 +470,12 @@ def run_plan(sizes, params, catalogues, cap_pairs, cap_rows, device, max_retries
 			tries[kind] += 1
 			if tries[kind] > max_retries:
 				raise NwayHipError('match table capacity could not be settled (%s, %d attempts; status flags %d)' % (kind, max_retries, flags))
+		if flags & FLAG_BARRIER:
+			# the fused front's workgroups wait for each other and did not get the GPU to themselves (another
+			# process' kernels on it): the registration as a launch of its own from now on
+			spend('path')
+			params.enable = int(params.enable) & ~ENABLE_FUSED_FRONT
+			continue
 		need = int(st[ST_SLOT_NEED])
 		if flags & FLAG_SLOT_OVERFLOW and not flags & (FLAG_LOOKBACK | FLAG_REG_OVERFLOW) and 0 < need <= LINK_SLOTS_CAP and tries['slots'] < 2:
 			# a primary with more candidates than the slots sized for the mean density (a clustered

@@ -38,9 +38,12 @@ plan, st = _hip.run_plan(sizes, params, cats, cap_pairs, cap_rows, dev, lean=Tru
 for _ in range(5):
 	plan.enqueue(cats)
 torch.cuda.synchronize()
-names = {0: ('k_register_x', ['start', 'ra/dec + sky_point', 'claims + stores landed', 'end']),
-	1: ('k_sweep', ['start', 'bitmap in LDS', 'wave 0 done streaming', 'all waves done', 'probes landed', 'end']),
+fused = plan.description['fused_front'] == 1
+names = {0: ('k_register_x', ['start', None, 'claims + stores landed', 'end']),
+	1: ('k_sweep', ['start', 'bitmap in LDS', 'wave 0 done streaming', 'all waves done', 'probes landed', 'end', 'barrier passed']),
 	2: ('k_tail2', ['start', 'cnt/slot/sigma landed', 'block scan', 'lookback', 'rows landed', 'group stats landed'])}
+if fused:
+	names[0] = ('registration inside the sweep launch (times since the first SWEEP workgroup started)', [None, None, 'claims + stores landed', 'announced'])
 acc = {}
 for rep in range(10):
 	buf.zero_()
@@ -48,17 +51,19 @@ for rep in range(10):
 	torch.cuda.synchronize()
 	t = buf.cpu().numpy().reshape(3, BLOCKS, STAMPS)
 	for k, (kname, labels) in names.items():
-		used = t[k][:, 0] > 0
+		ref = 1 if (fused and k == 0) else k
+		used = t[ref][:, 0] > 0
 		tk = t[k][used][:, :len(labels)].astype(np.float64) * 0.01  # 100 MHz -> us
-		t0 = tk[:, 0].min()
+		t0 = (t[ref][used][:, 0].astype(np.float64) * 0.01).min()
 		acc.setdefault(k, []).append((tk - t0, used.sum()))
 for k, (kname, labels) in names.items():
 	rel = np.stack([a for a, _ in acc[k]])  # reps x blocks x stamps
 	print('%s: %d workgroups; us since the first workgroup started (mean over workgroups | latest workgroup), mean of 10 runs' % (kname, acc[k][0][1]))
 	for i, lab in enumerate(labels):
-		print('    %-26s %7.2f | %7.2f' % (lab, rel[:, :, i].mean(), rel[:, :, i].max(axis=1).mean()))
-if len(names) == 3:
-	t = buf.cpu().numpy().reshape(3, BLOCKS, STAMPS).astype(np.float64) * 0.01
-	print('last run: register start -> sweep start %.2f us, sweep start -> tail start %.2f us, tail start -> tail end %.2f us' % (
-		t[1][t[1][:, 0] > 0][:, 0].min() - t[0][t[0][:, 0] > 0][:, 0].min(), t[2][t[2][:, 0] > 0][:, 0].min() - t[1][t[1][:, 0] > 0][:, 0].min(),
-		t[2][t[2][:, 0] > 0][:, 5].max() - t[2][t[2][:, 0] > 0][:, 0].min()))
+		if lab is not None and (fused or lab != 'barrier passed'):
+			print('    %-26s %7.2f | %7.2f' % (lab, rel[:, :, i].mean(), rel[:, :, i].max(axis=1).mean()))
+t = buf.cpu().numpy().reshape(3, BLOCKS, STAMPS).astype(np.float64) * 0.01
+first = t[1][t[1][:, 0] > 0][:, 0].min() if fused else t[0][t[0][:, 0] > 0][:, 0].min()
+print('last run: %s start -> sweep start %.2f us, sweep start -> tail start %.2f us, tail start -> tail end %.2f us' % (
+	'sweep' if fused else 'register', t[1][t[1][:, 0] > 0][:, 0].min() - first, t[2][t[2][:, 0] > 0][:, 0].min() - t[1][t[1][:, 0] > 0][:, 0].min(),
+	t[2][t[2][:, 0] > 0][:, 5].max() - t[2][t[2][:, 0] > 0][:, 0].min()))
