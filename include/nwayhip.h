@@ -47,7 +47,7 @@ extern "C" {
 #define NWAYHIP_ST_REGION_NEED 4         /* with NWAYHIP_FLAG_PAIR_OVERFLOW: links one workgroup wanted to keep, if that
                                             (and not the total) is what did not fit: come back with link_region_min */
 #define NWAYHIP_ST_SLOT_NEED 5           /* with NWAYHIP_FLAG_SLOT_OVERFLOW: the most candidates of one primary and catalogue (0: the
-                                            overflow was not of that kind); link_slots = that many, if <= 64, keeps the sparse front */
+                                            overflow was not of that kind); link_slots = that many, if <= 128, keeps the sparse front */
 #define NWAYHIP_ST_SURVIVORS 8           /* + c: secondaries of catalogue c passing the cell filter */
 #define NWAYHIP_ST_PAIRS 16              /* + c: (primary, secondary) links of catalogue c */
 #define NWAYHIP_ST_NOTFLAT 24            /* + c: 1 if catalogue c violates the flat-cell condition */
@@ -78,10 +78,11 @@ typedef struct nwayhip_match_params {
 	                                        total = dist_bayesfactor (no magnitude biases) */
 	int32_t link_slots;                  /* sparse front (any number of catalogues; needs radius_filter): the
 	                                        links of every secondary catalogue are kept in this many fixed
-	                                        slots per primary (at most 64), found by the sweep itself.
+	                                        slots per primary (at most 128), found by the sweep itself.
 	                                        0 = decide from the densities: 8 slots where every catalogue
-	                                        expects < 0.5 chance neighbours lambda per primary, else
-	                                        lambda + 6 sqrt(lambda) + 6, if that is at most 64 and the
+	                                        expects < 0.5 chance neighbours lambda per primary, else the
+	                                        Poisson quantile that one primary in a thousand RUNS exceeds
+	                                        (+ 2), if that is at most 128 and the
 	                                        primaries' cells fit the direct-mapped table; -1 = never (the
 	                                        general path); > 0 = force where possible.  What follows the
 	                                        front: nwayhip_plan_path() */

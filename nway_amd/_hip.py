@@ -18,7 +18,7 @@ MAXCAT = 8
 MAXPAIR = 28
 STATUS_WORDS = 32
 ST_ROWS, ST_FLAGS, ST_REGISTRATIONS, ST_TESTS, ST_REGION_NEED, ST_SLOT_NEED = 0, 1, 2, 3, 4, 5
-LINK_SLOTS_CAP = 64
+LINK_SLOTS_CAP = 128
 LINK_SLOTS_MAX_FUSED = 8  # most slots of the one-launch fused tails (sparse.inc: LINK_SLOTS_MAX)
 ST_SURVIVORS, ST_PAIRS, ST_NOTFLAT = 8, 16, 24
 FLAG_PAIR_OVERFLOW, FLAG_ROW_OVERFLOW, FLAG_REG_OVERFLOW, FLAG_SLOT_OVERFLOW, FLAG_LOOKBACK, FLAG_BARRIER = 1, 2, 4, 8, 16, 32

@@ -269,3 +269,17 @@ def test_fused_front_equals_separate_registration(k, flat):
 			if not key.startswith('_'):
 				np.testing.assert_array_equal(fused[key], plain[key], err_msg='%s (n0 = %d, n1 = %d)' % (key, n0, n1))
 		assert len(fused['ncat']) >= n0
+
+
+@pytest.mark.parametrize('k', [2, 3])
+def test_fields_with_more_than_64_links_per_primary(k):
+	"""~40 chance neighbours per primary: up to 128 slots the sparse front keeps such a field (dense 2-way tail;
+	k = 3: the general back end fed from the slots), also with the slots forced to the cap"""
+	import nway_amd as nw
+	from nway_amd import _hip
+	rng = np.random.default_rng(41 + k)
+	tabs = patch_tables(rng, [1500] + [66000] * (k - 1), 0.05, [rng.uniform(0.3, 1.5, size=1500)] + [0.1] * (k - 1))
+	t = both_paths(nw, tabs, 5.0)
+	assert 64 < t['_link_slots'] <= 128 and t['_desc']['tail'] == ('dense2' if k == 2 else 'hybrid')
+	assert len(t['ncat']) > 40 * 1500
+	both_paths(nw, tabs, 5.0, link_slots=128)

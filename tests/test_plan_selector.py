@@ -13,6 +13,17 @@ import pytest
 SKY = 4 * math.pi * (180 / math.pi)**2
 
 
+def poisson_slots(lam, n0):
+	"""plan.inc: the smallest s with n0 x P(Poisson(lam) > s) < 1e-3, + 2"""
+	p = math.exp(-lam)
+	cdf, s = p, 0
+	while (1 - cdf) * n0 > 1e-3 and s < 4096:
+		s += 1
+		p *= lam / s
+		cdf += p
+	return s + 2
+
+
 def describe(n, lam, radius=10.0, scheme=None, correction=0, radius_filter=True, link_slots=0, tuning=None):
 	"""n: catalogue sizes; lam: expected chance neighbours per primary of every secondary catalogue"""
 	from nway_amd import _hip
@@ -44,7 +55,7 @@ def test_half_a_chance_neighbour_per_primary():
 	a = describe([100000, 10000000], 0.499)
 	assert (a['path'], a['link_slots'], a['sweep'], a['tail'], a['split_capable']) == (1, 8, 'lds', 'sparse2', 1)
 	b = describe([100000, 10000000], 0.501)
-	assert b['link_slots'] == math.ceil(0.501 + 6 * math.sqrt(0.501) + 6) == 11 and b['tail'] == 'dense2' and b['path'] == 1
+	assert b['link_slots'] == poisson_slots(0.501, 100000) == 10 and b['tail'] == 'dense2' and b['path'] == 1
 	a3 = describe([100000, 1000000, 1000000], 0.499)
 	assert (a3['tail'], a3['link_slots'], a3['one_sweep'], a3['split_capable']) == ('sparsek', 8, 1, 1)
 	b3 = describe([100000, 1000000, 1000000], 0.501)
@@ -53,23 +64,32 @@ def test_half_a_chance_neighbour_per_primary():
 	assert (b4['tail'], b4['path'], b4['split_capable']) == ('hybrid', 2, 0)
 
 
-def test_the_sixty_four_slot_cap():
-	"""lambda + 6 sqrt(lambda) + 6 <= 64 keeps the sparse front; one slot more is the general path"""
-	root = (-6 + math.sqrt(36 + 4 * 58)) / 2
-	edge = root * root  # lambda + 6 sqrt(lambda) + 6 = 64
-	inside = describe([100000, 10000000], edge - 0.05, scheme=0)
-	assert inside['link_slots'] == 64 and inside['tail'] == 'dense2'
-	outside = describe([100000, 10000000], edge + 0.05, scheme=0)
+def test_the_slot_cap():
+	"""the Poisson quantile over all primaries (one overflowing primary per thousand runs, + 2) up to 128 slots keeps
+	the sparse front; one slot more is the general path.  BASELINE configs[0] (1 797 primaries, 27 chance neighbours
+	within 20 arcsec) is inside"""
+	n0 = 100000
+	lams = np.arange(40.0, 90.0, 0.05)
+	edge = [l for l in lams if poisson_slots(l, n0) <= 128][-1]
+	inside = describe([n0, 10000000], edge, scheme=0)
+	assert inside['link_slots'] == poisson_slots(edge, n0) and 126 <= inside['link_slots'] <= 128 and inside['tail'] == 'dense2'
+	outside = describe([n0, 10000000], edge + 0.5, scheme=0)
+	assert poisson_slots(edge + 0.5, n0) > 128
 	assert (outside['path'], outside['link_slots'], outside['sweep'], outside['tail']) == (0, 0, 'general', 'general')
+	cosmos = describe([1797, 560536], 27.2, radius=20.0, scheme=0)
+	assert (cosmos['path'], cosmos['link_slots'], cosmos['tail']) == (1, poisson_slots(27.2, 1797), 'dense2') and cosmos['link_slots'] == 58
+	# fewer primaries need fewer slots at the same density
+	assert describe([1000, 10000000], 10.0, scheme=0)['link_slots'] < describe([1000000, 10000000], 10.0, scheme=0)['link_slots']
 
 
 def test_dense_three_way_tail_up_to_31_slots():
 	from nway_amd import _hip
-	lam31 = [l for l in np.arange(5.0, 12.0, 0.01) if math.ceil(l + 6 * math.sqrt(l) + 6) == 31][-1]
-	assert describe([50000, 500000, 500000], lam31, scheme=0)['tail'] == 'dense3'
-	assert describe([50000, 500000, 500000], lam31 + 0.3, scheme=0)['tail'] == 'hybrid'
-	assert describe([50000, 500000, 500000], 3.0, scheme=0, tuning=dict(disable=_hip.DISABLE_DENSE3))['tail'] == 'hybrid'
-	assert describe([50000, 500000, 500000], 3.0, scheme=0, tuning=dict(disable=_hip.DISABLE_DENSE3 | _hip.DISABLE_HYBRID))['tail'] == 'general'
+	n = [50000, 500000, 500000]
+	lam31 = [l for l in np.arange(5.0, 12.0, 0.01) if poisson_slots(l, n[0]) == 31][-1]
+	assert describe(n, lam31, scheme=0)['tail'] == 'dense3'
+	assert describe(n, lam31 + 0.5, scheme=0)['tail'] == 'hybrid'
+	assert describe(n, 3.0, scheme=0, tuning=dict(disable=_hip.DISABLE_DENSE3))['tail'] == 'hybrid'
+	assert describe(n, 3.0, scheme=0, tuning=dict(disable=_hip.DISABLE_DENSE3 | _hip.DISABLE_HYBRID))['tail'] == 'general'
 
 
 def test_table_size_decides_the_sweep():
@@ -107,7 +127,7 @@ def test_correction_radius_filter_and_overrides():
 	assert describe([100000, 10000000], 0.1, link_slots=-1)['path'] == 0
 	forced = describe([100000, 10000000], 0.1, link_slots=24)
 	assert (forced['link_slots'], forced['tail']) == (24, 'dense2')
-	assert describe([100000, 10000000], 0.1, link_slots=200)['link_slots'] == 64
+	assert describe([100000, 10000000], 0.1, link_slots=200)['link_slots'] == 128
 	t = describe([100000, 10000000], 0.1, tuning=dict(direct_log2=21, fold_log2=19))
 	assert (t['sweep'], t['direct_log2'], t['fold_log2']) == ('big', 21, 19)
 
