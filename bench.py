@@ -246,8 +246,14 @@ def main():
 	rank = int(os.environ.get('RANK', '0'))
 	local_rank = int(os.environ.get('LOCAL_RANK', '0'))
 	ngpu = max(torch.cuda.device_count(), 1)
-	if world > 1:
+	force_dist = world == 1 and os.environ.get('NWAY_BENCH_FORCE_DIST') == '1'  # (one rank through the engines and RCCL: a dry run of the N > 1 code)
+	if world > 1 or force_dist:
 		import torch.distributed as dist
+		if force_dist:
+			os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+			os.environ.setdefault('MASTER_PORT', '29533')
+			os.environ.setdefault('RANK', '0')
+			os.environ.setdefault('WORLD_SIZE', '1')
 		# "nccl" is RCCL on ROCm.  NWAY_BENCH_BACKEND=gloo lets several ranks share one GPU
 		# (functional testing of the sharded path on a 1-GPU box only).
 		backend = os.environ.get('NWAY_BENCH_BACKEND', 'nccl')
@@ -266,8 +272,8 @@ def main():
 
 	io = None
 	engine = None
-	strong = args.scaling == 'strong' and world > 1
-	if world > 1 and not strong:
+	strong = args.scaling == 'strong' and (world > 1 or force_dist)
+	if (world > 1 or force_dist) and not strong:
 		# weak scaling: every rank owns n_primary primaries (a contiguous row shard of the global
 		# primary catalogue, N x n_primary rows) and loads a 1/world slice of the ONE secondary
 		# catalogue (n_secondary rows in total); the slices are all-gathered once at set-up so that
@@ -356,7 +362,7 @@ def main():
 
 	def barrier():
 		torch.cuda.synchronize(device)
-		if world > 1:
+		if world > 1 or force_dist:
 			dist.barrier()
 			torch.cuda.synchronize(device)
 
@@ -381,7 +387,7 @@ def main():
 		launches = [a + b for a, b in zip(launches, n_)]
 		ms = [a + b for a, b in zip(ms, ms_)]
 		pl.profile(0)
-	if world > 1:
+	if world > 1 or force_dist:
 		tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
 		dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
 		elapsed = float(tmax.item())
@@ -479,7 +485,7 @@ def main():
 		else:
 			out['cpu_baseline'] = None
 		print(json.dumps(out))
-	if world > 1:
+	if world > 1 or force_dist:
 		dist.destroy_process_group()
 
 

@@ -9,7 +9,7 @@ the secondary densities only (nu_0 cancels against nu+_0 = nu_0, __init__.py:214
 a shard's rows are bit-identical to the same rows of the unsharded run.
 
 The one exchange step is the distribution of the secondary catalogues: each rank loads a
-slice and an all-gatherv (grouped broadcasts; RCCL has no native allgatherv) leaves the
+slice and an all-gatherv (one RCCL all-gather of equally padded pieces) leaves the
 full ra / dec / error columns resident on every GPU.  It happens once per catalogue, not
 once per primary batch; ``ShardedMatch.setup`` times it separately.  No collective is on
 the per-batch path; the host concatenates per-rank tables in rank order when a global
@@ -36,7 +36,12 @@ def world_info(group=None):
 
 def allgatherv(tensor, group=None):
 	"""Concatenation over ranks (rank order) of 1-D tensors of different lengths.
-	Returns (full tensor, list of per-rank counts)."""
+	Returns (full tensor, list of per-rank counts).
+
+	RCCL ("nccl"): ONE all-gather of equal pieces -- every rank pads its slice to the longest (the slices of a
+	catalogue differ by a row or two; RCCL has no native all-gatherv and the pieces of a ring all-gather must be
+	equal), the padding is dropped when the pieces are copied into place.  gloo (CPU tests, ranks sharing a GPU):
+	one broadcast per rank."""
 	import torch
 	dist = _dist()
 	rank, world = world_info(group)
@@ -50,8 +55,18 @@ def allgatherv(tensor, group=None):
 	offsets = numpy.concatenate([[0], numpy.cumsum(counts)])
 	pieces = [full[offsets[r]:offsets[r + 1]] for r in range(world)]
 	if dist.get_backend(group) == 'nccl':
-		# uneven all_gather = one coalesced group of broadcasts inside RCCL
-		dist.all_gather(pieces, tensor.contiguous(), group=group)
+		longest = max(counts)
+		if longest == 0:
+			return full, counts
+		if min(counts) == longest:
+			dist.all_gather_into_tensor(full, tensor.contiguous(), group=group)
+		else:
+			mine = torch.zeros(longest, dtype=tensor.dtype, device=tensor.device)
+			mine[:counts[rank]] = tensor
+			padded = torch.empty(world * longest, dtype=tensor.dtype, device=tensor.device)
+			dist.all_gather_into_tensor(padded, mine, group=group)
+			for r in range(world):
+				pieces[r].copy_(padded[r * longest:r * longest + counts[r]])
 	else:
 		pieces[rank].copy_(tensor)
 		works = []

@@ -25,7 +25,7 @@ def dist(apos, bpos):
 	t = _hip.torch()
 	args = (a_ra, a_dec, b_ra, b_dec)
 	# numpy.result_type treats Python scalars as weak (NEP 50); 0-d arrays and numpy scalars carry their own dtype
-	promoted = numpy.result_type(*[x if isinstance(x, (int, float)) and not isinstance(x, bool) else numpy.asarray(x) for x in args])
+	promoted = numpy.result_type(*[x if type(x) in (int, float) else numpy.asarray(x) for x in args])
 	given = [numpy.asarray(x) for x in args]
 	if promoted == numpy.float32 and any(g.ndim > 0 for g in given):
 		arrs = numpy.broadcast_arrays(*[g.astype(numpy.float32) for g in given])

@@ -283,3 +283,16 @@ def test_fields_with_more_than_64_links_per_primary(k):
 	assert 64 < t['_link_slots'] <= 128 and t['_desc']['tail'] == ('dense2' if k == 2 else 'hybrid')
 	assert len(t['ncat']) > 40 * 1500
 	both_paths(nw, tabs, 5.0, link_slots=128)
+
+
+def test_dense_three_way_field_with_tens_of_links_per_catalogue():
+	"""the tuple-parallel 3-way tail beyond 31 slots (64-bit validity words): ~20 and ~12 chance neighbours per primary,
+	hundreds of tuples each -- the shape of BASELINE configs[1]"""
+	import nway_amd as nw
+	rng = np.random.default_rng(47)
+	tabs = patch_tables(rng, [400, 33000, 20000], 0.05, [rng.uniform(0.5, 1.5, size=400), 0.1, 0.5])
+	t = both_paths(nw, tabs, 5.0)
+	assert 31 < t['_link_slots'] <= 63 and t['_desc']['tail'] == 'dense3'
+	assert len(t['ncat']) > 150 * 400
+	t = both_paths(nw, tabs, 5.0, link_slots=63, correction=1)
+	assert t['_desc']['tail'] == 'dense3'

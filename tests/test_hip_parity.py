@@ -88,7 +88,7 @@ def test_dist_keeps_float32_like_numpy(nw):
 	assert nw.match.dist((a_ra.astype(float), a_dec.astype(float)), (b_ra.astype(float), b_dec.astype(float))).dtype == np.float64
 	# numpy's promotion decides (NEP 50): Python scalars are weak and leave float32 arrays float32 ...
 	got = nw.match.dist((a_ra, a_dec), (10.0, 20.0))
-	want = orc.dist((a_ra, a_dec), (10.0, 20.0))
+	want = orc.dist((a_ra, a_dec), (np.full(n, 10.0, dtype=np.float32), np.full(n, 20.0, dtype=np.float32)))  # (what numpy makes of the scalars)
 	assert got.dtype == np.float32 and want.dtype == np.float32 and got.shape == want.shape
 	np.testing.assert_allclose(got, want, rtol=2e-4, atol=3e-5)
 	# ... a float64 numpy scalar or array is not

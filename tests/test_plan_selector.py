@@ -82,12 +82,16 @@ def test_the_slot_cap():
 	assert describe([1000, 10000000], 10.0, scheme=0)['link_slots'] < describe([1000000, 10000000], 10.0, scheme=0)['link_slots']
 
 
-def test_dense_three_way_tail_up_to_31_slots():
+def test_dense_three_way_tail_up_to_63_slots():
+	"""k = 3: the tuple-parallel tail keeps a 64-bit word of validity bits per (primary, link of the first secondary
+	catalogue): 63 slots; beyond that the general back end fed from the slots.  BASELINE configs[1] is inside"""
 	from nway_amd import _hip
 	n = [50000, 500000, 500000]
-	lam31 = [l for l in np.arange(5.0, 12.0, 0.01) if poisson_slots(l, n[0]) == 31][-1]
-	assert describe(n, lam31, scheme=0)['tail'] == 'dense3'
-	assert describe(n, lam31 + 0.5, scheme=0)['tail'] == 'hybrid'
+	lam63 = [l for l in np.arange(20.0, 40.0, 0.01) if poisson_slots(l, n[0]) == 63][-1]
+	assert describe(n, lam63, scheme=0)['tail'] == 'dense3'
+	assert describe(n, lam63 + 0.5, scheme=0)['tail'] == 'hybrid'
+	cosmos = describe([1797, 560536, 345512], 27.2, radius=20.0, scheme=0)
+	assert (cosmos['link_slots'], cosmos['tail'], cosmos['path']) == (58, 'dense3', 1)
 	assert describe(n, 3.0, scheme=0, tuning=dict(disable=_hip.DISABLE_DENSE3))['tail'] == 'hybrid'
 	assert describe(n, 3.0, scheme=0, tuning=dict(disable=_hip.DISABLE_DENSE3 | _hip.DISABLE_HYBRID))['tail'] == 'general'
 

@@ -131,3 +131,64 @@ def test_bench_under_torchrun_two_ranks(tmp_path, scaling):
 	if os.path.isdir(keep):
 		with open(os.path.join(keep, 'bench_x2_%s.json' % scaling), 'w') as f:
 			f.write(line + '\n')
+
+
+def rccl_worker(rank, world, port, outfile):
+	os.environ['MASTER_ADDR'] = '127.0.0.1'
+	os.environ['MASTER_PORT'] = str(port)
+	os.environ['HSA_ENABLE_IPC_MODE_LEGACY'] = '0'
+	dev = torch.device('cuda', 0)
+	torch.cuda.set_device(dev)
+	dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+	try:
+		sys.path.insert(0, ROOT)
+		from nway_amd import distributed
+		x = torch.arange(5, dtype=torch.float64, device=dev)
+		# every collective the engines and bench.py issue, through RCCL itself
+		got = [torch.zeros(1, dtype=torch.int64, device=dev)]
+		dist.all_gather(got, torch.tensor([7], dtype=torch.int64, device=dev))
+		full = torch.empty(5, dtype=torch.float64, device=dev)
+		dist.all_gather_into_tensor(full, x)
+		a2a = torch.empty(64, dtype=torch.uint8, device=dev)
+		dist.all_to_all_single(a2a, torch.arange(64, dtype=torch.uint8, device=dev))
+		m = torch.tensor([3.5], dtype=torch.float64, device=dev)
+		dist.all_reduce(m, op=dist.ReduceOp.MAX)
+		dist.broadcast(x, src=0)
+		dist.barrier()
+		torch.cuda.synchronize(dev)
+		ok = int(got[0].item()) == 7 and torch.equal(full, x) and torch.equal(a2a.cpu(), torch.arange(64, dtype=torch.uint8)) and float(m.item()) == 3.5
+		# and the engine on top of it (one rank: the collectives of set-up and total_rows)
+		tabs = catalogues(2, False)
+		sm = distributed.ShardedMatch(tabs[0], [tabs[1]], 10., 0.9, device=dev)
+		sm.step()
+		rows = sm.total_rows()
+		np.savez(outfile, ok=ok, rows=rows, backend=dist.get_backend())
+	finally:
+		dist.destroy_process_group()
+
+
+def test_rccl_is_there_and_carries_the_engines_collectives(tmp_path):
+	"""one rank, backend "nccl" (= RCCL on ROCm): the process group comes up on the GPU box and every kind of
+	collective nway_amd.distributed and bench.py issue goes through the library (more than one rank needs more
+	than one GPU: the driver's scaling run)"""
+	import nway_amd as nw
+	outfile = str(tmp_path / 'rccl.npz')
+	mp.spawn(rccl_worker, args=(1, free_port(), outfile), nprocs=1, join=True)
+	got = np.load(outfile)
+	assert bool(got['ok']) and str(got['backend']) == 'nccl'
+	want = nw.nway_match(catalogues(2, False), 10., 0.9, logger=nw.NullOutputLogger())
+	assert int(got['rows']) == len(want)
+
+
+@pytest.mark.parametrize('scaling', ['weak', 'strong'])
+def test_bench_one_rank_through_rccl(scaling):
+	"""bench.py's N > 1 code -- engines, barriers, the MAX over ranks -- with ONE rank on the real backend ("nccl" = RCCL):
+	NWAY_BENCH_FORCE_DIST=1 (the driver's 2 / 4 / 8-GPU runs take the same lines with more ranks)"""
+	env = dict(os.environ, NWAY_BENCH_FORCE_DIST='1', HSA_ENABLE_IPC_MODE_LEGACY='0', MASTER_PORT=str(free_port()))
+	cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '5', '--warmup', '2', '--prewarm', '3', '--n-primary', '20000',
+		'--n-secondary', '2000000', '--scaling', scaling, '--cpu-sample', '0']
+	res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, timeout=600, env=env, cwd=ROOT)
+	assert res.returncode == 0, res.stderr[-3000:]
+	out = json.loads([l for l in res.stdout.splitlines() if l.startswith('{')][-1])
+	assert out['n_gpus'] == 1 and out['scaling'] == scaling and 20000 * 1.7 < out['config']['rows_per_step'] < 20000 * 1.9
+	assert out['config']['parallelism'].startswith('secondary-stream' if scaling == 'strong' else 'primary-row')
