@@ -22,6 +22,7 @@ for seed in range(lo, hi):
 	if seed % 2 == 1 and k > 4:
 		tabs = tabs[:4]
 	comp = float(rng.choice([1.0, 0.9, 0.5]))
+	excused0 = fz.TIE_EXCUSES['rows']
 	try:
 		rows += fz.compare(nw, tabs, radius, comp, 'cli' if seed % 3 == 0 else 'api', f32=(seed % 5 == 0))
 	except Exception as e:
@@ -29,4 +30,5 @@ for seed in range(lo, hi):
 		print('seed %d FAILED: %s' % (seed, str(e).strip().splitlines()[0][:200]))
 		if not isinstance(e, AssertionError):
 			traceback.print_exc()
+print('match_flag differences excused by a rounding-level tie: %d rows in %d configurations' % (fz.TIE_EXCUSES['rows'], fz.TIE_EXCUSES['configurations']))
 print('%d configurations, %d rows, %d failures %s in %.0f s' % (hi - lo, rows, len(bad), bad, time.time() - t0))

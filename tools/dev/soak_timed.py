@@ -35,6 +35,7 @@ for seed in range(lo, hi):
 	if seed % 2 == 1 and k > 4:
 		tabs = tabs[:4]
 	comp = float(rng.choice([1.0, 0.9, 0.5]))
+	excused0 = fz.TIE_EXCUSES['rows']
 	t0 = time.time()
 	signal.alarm(limit)
 	try:
@@ -46,6 +47,9 @@ for seed in range(lo, hi):
 		print('seed %d FAILED: %s' % (seed, str(e).strip().splitlines()[0][:200]), flush=True)
 	finally:
 		signal.alarm(0)
+	if fz.TIE_EXCUSES['rows'] != excused0:
+		print('seed %d: %d match_flag difference(s) excused by a rounding-level tie' % (seed, fz.TIE_EXCUSES['rows'] - excused0), flush=True)
 	if os.environ.get('SOAK_VERBOSE'):
 		print(seed, k, '%.2f s' % (time.time() - t0), flush=True)
+print('match_flag differences excused by a rounding-level tie: %d rows in %d configurations' % (fz.TIE_EXCUSES['rows'], fz.TIE_EXCUSES['configurations']))
 print('%d configurations, %d rows, %d failures %s, %d skipped as too slow for the oracle %s in %.0f s' % (hi - lo, rows, len(bad), bad, len(skipped), skipped, time.time() - t_all))

@@ -82,3 +82,38 @@ for world in (1, 2, 4, 8):
 	print('| %d | register %.1f + sweep %.1f | ~%d records = %.0f KB | tail %.1f (+ import) | %.1f |' % (
 		world, stage['register'], stage['sweep'], links, links * 48 / 1e3, stage['rows'], both))
 	plan.close()
+
+# ---- what the host round trip between the two halves costs (the collectives are torch.distributed calls, not part of
+# the C ABI): ONE rank -- SecondarySplitMatch.step() = front half, exchange (a device copy at world 1; the all-to-all
+# otherwise), back half, each enqueued from Python -- against the unsplit pipeline enqueued with one call
+eng = distributed.SecondarySplitMatch(primary, [dict(secondary, error=0.1)], radius, 0.9, dev)
+for _ in range(20):
+	eng.step()
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(100):
+	eng.step()
+torch.cuda.synchronize()
+split_us = (time.perf_counter() - t0) / 100 * 1e6
+t0 = time.perf_counter()
+for _ in range(100):
+	eng.plan.split_front(eng.cats, eng.split)
+	eng.plan.split_back(eng.cats, eng.split)
+torch.cuda.synchronize()
+halves_us = (time.perf_counter() - t0) / 100 * 1e6
+params = _hip.make_params(2, _hip.SCHEME_SPHERE, radius, err, dens, dens_plus, nway_amd._prior_table(dens, dens_plus, comp))
+cats = [_hip.DeviceCatalogue(primary['ra'], primary['dec'], primary['error'], dev), _hip.DeviceCatalogue(secondary['ra'], secondary['dec'], 0.1, dev)]
+cap_pairs, cap_rows = nway_amd._estimate_capacities([n0, n1], [bench.SKY_AREA] * 2, radius, _hip.SCHEME_SPHERE, True)
+plan, _ = _hip.run_plan([n0, n1], params, cats, cap_pairs, cap_rows, dev, lean=True)
+for _ in range(20):
+	plan.enqueue(cats)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(100):
+	plan.enqueue(cats)
+torch.cuda.synchronize()
+whole_us = (time.perf_counter() - t0) / 100 * 1e6
+print()
+print('one rank, %d x %d, per step (wall clock, 100 steps, one secondary buffer): unsplit pipeline, one enqueue %.1f us | both halves back to back '
+	'(two enqueues, no exchange) %.1f us | SecondarySplitMatch.step(): front, device copy of the %d-byte export buffer, back %.1f us' % (
+	n0, n1, whole_us, halves_us, eng.export.numel(), split_us))
