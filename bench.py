@@ -233,6 +233,8 @@ def main():
 	ap.add_argument('--profile-stages', action='store_true', help='also time every stage (adds event records to the region)')
 	ap.add_argument('--prewarm', type=int, default=200, help='untimed steps before the W warm-up steps: the first ~10 ms after an idle period run at lower clocks (20 steps right after start-up: 82 us each, after 200: 78.5)')
 	ap.add_argument('--two-pipelines', type=int, default=1, help='also time the steps alternating over two independent pipelines (reported beside, never as, `value`); 0 = skip')
+	ap.add_argument('--comm', choices=['torch', 'rccl'], default=os.environ.get('NWAY_BENCH_COMM', 'torch'),
+		help='who carries the exchanges of the multi-GPU modes: torch.distributed (default) or the library\'s own RCCL calls behind the C ABI (nwayhip_comm_*)')
 	ap.add_argument('--fused-front', action='store_true', help='development: the registration inside the sweep launch (NWAYHIP_ENABLE_FUSED_FRONT)')
 	ap.add_argument('--streams', type=int, default=int(os.environ.get('NWAY_BENCH_STREAMS', '1')),
 		help='independent pipelines (own workspace, own output table, own HIP stream) the steps alternate over')
@@ -282,7 +284,7 @@ def main():
 		n_sec_local = args.n_secondary // world + (args.n_secondary % world if rank == world - 1 else 0)
 		primary, secondary = make_workload(args.n_primary, n_sec_local, args.seed + 1000 * rank)
 		from nway_amd import distributed
-		engine = distributed.ShardedMatch(primary, [secondary], args.radius, args.completeness, device, tuning=tuning)
+		engine = distributed.ShardedMatch(primary, [secondary], args.radius, args.completeness, device, tuning=tuning, comm=('rccl' if args.comm == 'rccl' else None))
 	elif strong:
 		# strong scaling: ONE job of n_primary x n_secondary.  Every rank generates the same
 		# catalogues (same seed) and keeps its slice of the secondaries and its shard of the primaries
@@ -292,7 +294,7 @@ def main():
 		pb = distributed.shard_bounds(args.n_primary, world)
 		sec_slice = dict(secondary, ra=secondary['ra'][sb[rank]:sb[rank + 1]], dec=secondary['dec'][sb[rank]:sb[rank + 1]])
 		prim_shard = dict(primary, ra=primary['ra'][pb[rank]:pb[rank + 1]], dec=primary['dec'][pb[rank]:pb[rank + 1]], error=primary['error'][pb[rank]:pb[rank + 1]])
-		engine = distributed.SecondarySplitMatch(prim_shard, [sec_slice], args.radius, args.completeness, device, tuning=tuning)
+		engine = distributed.SecondarySplitMatch(prim_shard, [sec_slice], args.radius, args.completeness, device, tuning=tuning, comm=('rccl' if args.comm == 'rccl' else None))
 	else:
 		primary, secondary = make_workload(args.n_primary, args.n_secondary, args.seed)
 
@@ -304,6 +306,14 @@ def main():
 		dens, dens_plus = nway_amd._compute_source_densities(tables, log)
 		comp = nway_amd._completeness_vector(args.completeness, 2)
 		params = _hip.make_params(2, scheme, args.radius, err, dens, dens_plus, nway_amd._prior_table(dens, dens_plus, comp), tuning=tuning)
+		torch.cuda.synchronize(device)
+		t0 = time.perf_counter()
+		cats = [_hip.DeviceCatalogue(t['ra'], t['dec'], np.asarray(t['error'], dtype=float), device) for t in tables]
+		torch.cuda.synchronize(device)
+		h2d_first_s = time.perf_counter() - t0
+		# the same once more: the first upload of a process also pays for the context, the allocator's first blocks and
+		# the first touch of the freshly generated host arrays
+		del cats
 		torch.cuda.synchronize(device)
 		t0 = time.perf_counter()
 		cats = [_hip.DeviceCatalogue(t['ra'], t['dec'], np.asarray(t['error'], dtype=float), device) for t in tables]
@@ -350,7 +360,7 @@ def main():
 		for col in plan.cols['idx'] + plan.cols['sep']:
 			d2h_bytes += col[:rows_per_step].cpu().numpy().nbytes
 		d2h_s = time.perf_counter() - t0
-		io = dict(h2d_ms=h2d_s * 1e3, h2d_bytes=int(h2d_bytes), h2d_mode=_hip.upload_mode['last'], d2h_ms=d2h_s * 1e3, d2h_bytes=int(d2h_bytes),
+		io = dict(h2d_ms=h2d_s * 1e3, h2d_first_ms=h2d_first_s * 1e3, h2d_bytes=int(h2d_bytes), h2d_mode=_hip.upload_mode['last'], d2h_ms=d2h_s * 1e3, d2h_bytes=int(d2h_bytes),
 			note='host arrays -> HBM before the timed region (page-locked in place for the copy engine), table -> host after it; never part of `value`')
 	else:
 		step = engine.step

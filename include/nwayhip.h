@@ -264,6 +264,25 @@ int nwayhip_split_front_enqueue(nwayhip_plan* plan, const nwayhip_catalogue* h_c
 int nwayhip_split_back_enqueue(nwayhip_plan* plan, const nwayhip_catalogue* h_cats, void* workspace, size_t workspace_bytes,
 	const nwayhip_split* h_split, const nwayhip_table* h_table, int64_t* d_status, void* stream);
 
+/* ---- RCCL behind the ABI: the two exchanges of the multi-GPU modes as library calls ------
+ * One process per GPU.  Rank 0 makes the id, the host hands its NWAYHIP_COMM_ID_BYTES bytes to every rank
+ * (any side channel), every rank calls nwayhip_comm_init with its device current; the calls are collective.
+ * librccl is opened when the first of these is called (a process that never shards does not need it).
+ * nway_amd/distributed.py takes this route with comm='rccl'; its default remains torch.distributed. */
+#define NWAYHIP_COMM_ID_BYTES 128
+typedef struct nwayhip_comm nwayhip_comm;
+int nwayhip_comm_unique_id(void* h_id /*[NWAYHIP_COMM_ID_BYTES]*/);
+int nwayhip_comm_init(nwayhip_comm** comm, int32_t world, int32_t rank, const void* h_id);
+int nwayhip_comm_destroy(nwayhip_comm* comm);
+int32_t nwayhip_comm_world(const nwayhip_comm* comm);
+int32_t nwayhip_comm_rank(const nwayhip_comm* comm);
+/* all-gatherv of one double column: rank r contributes h_counts[r] rows (d_send), d_recv receives the sum(h_counts)
+ * rows of all ranks in rank order -- one group of broadcasts on `stream` */
+int nwayhip_comm_allgatherv_f64(nwayhip_comm* comm, const double* d_send, const int64_t* h_counts /*[world]*/, double* d_recv, void* stream);
+/* the candidate exchange of the secondary-split mode: block r (block_bytes bytes) of d_export to rank r, block s of
+ * d_import from rank s; one group of send / recv pairs on `stream`, between the two halves below, no host round trip */
+int nwayhip_comm_exchange(nwayhip_comm* comm, const void* d_export, void* d_import, size_t block_bytes, void* stream);
+
 /* Stage timing with HIP events recorded on the pipeline's own stream (bench.py's roofline leg).
  * stage_mask: bit s set => every launch group of stage s in subsequent nwayhip_match_enqueue
  * calls is bracketed by an event pair (ring of NWAYHIP_PROFILE_RING pairs per stage); the

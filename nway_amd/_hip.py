@@ -104,6 +104,13 @@ SYMBOLS = {
 	'nwayhip_bias_lookup': (ctypes.c_int, [_i64, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp]),
 	'nwayhip_catalogue_extent': (ctypes.c_int, [_vp, _vp, _i64, _vp, _vp]),
 	'nwayhip_read_probe': (ctypes.c_int, [_vp, _vp, _i64, _vp, _i32, _vp]),
+	'nwayhip_comm_unique_id': (ctypes.c_int, [_vp]),
+	'nwayhip_comm_init': (ctypes.c_int, [ctypes.POINTER(_vp), _i32, _i32, _vp]),
+	'nwayhip_comm_destroy': (ctypes.c_int, [_vp]),
+	'nwayhip_comm_world': (ctypes.c_int32, [_vp]),
+	'nwayhip_comm_rank': (ctypes.c_int32, [_vp]),
+	'nwayhip_comm_allgatherv_f64': (ctypes.c_int, [_vp, _vp, ctypes.POINTER(_i64), _vp, _vp]),
+	'nwayhip_comm_exchange': (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_size_t, _vp]),
 }
 
 _lib = None
@@ -258,6 +265,59 @@ def scheme_from_extents(extents, err):
 		if not (err < 1 and lo > 10 * err and hi < 360 - 10 * err and absdec < 45):
 			return SCHEME_SPHERE
 	return SCHEME_FLAT
+
+
+COMM_ID_BYTES = 128
+
+
+class RcclComm(object):
+	"""RCCL communicator behind the C ABI (nwayhip_comm_*): one per process / GPU.  ``id_bytes``: the 128 bytes rank 0 got
+	from ``RcclComm.unique_id()``, handed over by the caller's side channel (nway_amd.distributed broadcasts them)."""
+
+	@staticmethod
+	def unique_id():
+		buf = (ctypes.c_char * COMM_ID_BYTES)()
+		check(load().nwayhip_comm_unique_id(ctypes.cast(buf, ctypes.c_void_p)))
+		return bytes(buf.raw)
+
+	def __init__(self, world, rank, id_bytes, device):
+		self.lib = load()
+		self.device = require_device(device)
+		self.world, self.rank = int(world), int(rank)
+		if len(id_bytes) != COMM_ID_BYTES:
+			raise ValueError('the communicator id has %d bytes' % COMM_ID_BYTES)
+		handle = ctypes.c_void_p(0)
+		buf = ctypes.create_string_buffer(bytes(id_bytes), COMM_ID_BYTES)
+		with torch().cuda.device(self.device):
+			check(self.lib.nwayhip_comm_init(ctypes.byref(handle), self.world, self.rank, ctypes.cast(buf, ctypes.c_void_p)))
+		self.handle = handle
+
+	def allgatherv(self, tensor, counts):
+		"""every rank's 1-D float64 slice -> the whole column (rank order) on every GPU; counts: rows of every rank"""
+		t = torch()
+		full = t.empty(int(sum(counts)), dtype=t.float64, device=self.device)
+		arr = (ctypes.c_int64 * self.world)(*[int(c) for c in counts])
+		src = tensor.contiguous()
+		check(self.lib.nwayhip_comm_allgatherv_f64(self.handle, ptr(src) if int(counts[self.rank]) > 0 else None, arr, ptr(full), current_stream_ptr(self.device)))
+		return full
+
+	def exchange(self, export, imported):
+		"""block r of ``export`` to rank r, block s of ``imported`` from rank s (uint8 tensors of world equal blocks)"""
+		nbytes = int(export.numel()) * export.element_size()
+		if nbytes % self.world or nbytes != int(imported.numel()) * imported.element_size():
+			raise ValueError('exchange buffers must hold one equal block per rank')
+		check(self.lib.nwayhip_comm_exchange(self.handle, ptr(export), ptr(imported), nbytes // self.world, current_stream_ptr(self.device)))
+
+	def close(self):
+		if getattr(self, 'handle', None):
+			self.lib.nwayhip_comm_destroy(self.handle)
+			self.handle = None
+
+	def __del__(self):
+		try:
+			self.close()
+		except Exception:
+			pass
 
 
 class DeviceCatalogue(object):

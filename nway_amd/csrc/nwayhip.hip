@@ -55,3 +55,4 @@
 #include "elementwise.inc"
 #include "api.inc"
 #include "plan.inc"
+#include "comm.inc"

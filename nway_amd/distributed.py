@@ -34,9 +34,25 @@ def world_info(group=None):
 	return 0, 1
 
 
-def allgatherv(tensor, group=None):
+def make_comm(device, group=None):
+	"""an RCCL communicator behind the C ABI (``_hip.RcclComm``) over the ranks of ``group``: rank 0 makes the id, one
+	broadcast over the process group that launched the ranks hands it out"""
+	from nway_amd import _hip
+	dist = _dist()
+	rank, world = world_info(group)
+	ident = [_hip.RcclComm.unique_id() if rank == 0 else None]
+	if world > 1:
+		src = 0 if group is None else dist.get_global_rank(group, 0)
+		dist.broadcast_object_list(ident, src=src, group=group)
+	return _hip.RcclComm(world, rank, ident[0], device)
+
+
+def allgatherv(tensor, group=None, comm=None):
 	"""Concatenation over ranks (rank order) of 1-D tensors of different lengths.
 	Returns (full tensor, list of per-rank counts).
+
+	comm (an ``_hip.RcclComm``): the column travels through the library's own RCCL calls (nwayhip_comm_allgatherv_f64:
+	one group of broadcasts); only the row counts go through torch.distributed.
 
 	RCCL ("nccl"): ONE all-gather of equal pieces -- every rank pads its slice to the longest (the slices of a
 	catalogue differ by a row or two; RCCL has no native all-gatherv and the pieces of a ring all-gather must be
@@ -46,11 +62,14 @@ def allgatherv(tensor, group=None):
 	dist = _dist()
 	rank, world = world_info(group)
 	if world == 1:
-		return tensor, [int(tensor.shape[0])]
+		n = int(tensor.shape[0])
+		return (tensor if comm is None else comm.allgatherv(tensor, [n])), [n]
 	count = torch.tensor([tensor.shape[0]], dtype=torch.int64, device=tensor.device)
 	counts = [torch.zeros(1, dtype=torch.int64, device=tensor.device) for _ in range(world)]
 	dist.all_gather(counts, count, group=group)
 	counts = [int(c.item()) for c in counts]
+	if comm is not None:
+		return comm.allgatherv(tensor, counts), counts
 	full = torch.empty(sum(counts), dtype=tensor.dtype, device=tensor.device)
 	offsets = numpy.concatenate([[0], numpy.cumsum(counts)])
 	pieces = [full[offsets[r]:offsets[r + 1]] for r in range(world)]
@@ -101,9 +120,10 @@ class ShardedMatch(object):
 	"""
 
 	def __init__(self, primary, secondaries, match_radius, prior_completeness, device, group=None,
-			prob_ratio_secondary=0.5, tuning=None):
+			prob_ratio_secondary=0.5, tuning=None, comm=None):
 		if isinstance(secondaries, dict):
 			secondaries = [secondaries]
+		self.comm = make_comm(device, group) if comm == 'rccl' else comm  # None: torch.distributed moves the columns
 		self.primary = primary
 		self.secondary_slices = secondaries
 		self.match_radius = float(match_radius)
@@ -135,13 +155,13 @@ class ShardedMatch(object):
 		self.full_secondaries = []
 		self.gathered_bytes = 0
 		for sl in self.secondary_slices:
-			ra, _ = allgatherv(torch.as_tensor(numpy.asarray(sl['ra'], dtype=float)).to(dev), self.group)
-			dec, counts = allgatherv(torch.as_tensor(numpy.asarray(sl['dec'], dtype=float)).to(dev), self.group)
+			ra, _ = allgatherv(torch.as_tensor(numpy.asarray(sl['ra'], dtype=float)).to(dev), self.group, self.comm)
+			dec, counts = allgatherv(torch.as_tensor(numpy.asarray(sl['dec'], dtype=float)).to(dev), self.group, self.comm)
 			self.gathered_bytes += 16 * int(ra.shape[0])
 			if numpy.ndim(sl['error']) == 0:
 				err = float(sl['error'])
 			else:
-				err, _ = allgatherv(torch.as_tensor(numpy.asarray(sl['error'], dtype=float)).to(dev), self.group)
+				err, _ = allgatherv(torch.as_tensor(numpy.asarray(sl['error'], dtype=float)).to(dev), self.group, self.comm)
 				self.gathered_bytes += 8 * int(ra.shape[0])
 			self.full_secondaries.append(dict(name=sl['name'], ra=ra, dec=dec, error=err, area=sl['area'], counts=counts))
 		# global size of the primary catalogue (only logged; the priors do not depend on it)
@@ -308,9 +328,10 @@ class SecondarySplitMatch(object):
 	"""
 
 	def __init__(self, primary, secondaries, match_radius, prior_completeness, device, group=None,
-			prob_ratio_secondary=0.5, capacity=None, tuning=None):
+			prob_ratio_secondary=0.5, capacity=None, tuning=None, comm=None):
 		if isinstance(secondaries, dict):
 			secondaries = [secondaries]
+		self.comm = make_comm(device, group) if comm == 'rccl' else comm  # None: torch.distributed carries the exchanges
 		self.primary = primary
 		self.secondary_slices = secondaries
 		self.match_radius = float(match_radius)
@@ -340,9 +361,9 @@ class SecondarySplitMatch(object):
 		dev = self._exchange_device()
 		f64 = lambda x: torch.as_tensor(numpy.ascontiguousarray(numpy.asarray(x, dtype=float))).to(dev)
 		# every rank needs ALL primaries: coordinates for the registration, errors for nothing but symmetry
-		ra, counts = allgatherv(f64(self.primary['ra']), self.group)
-		dec, _ = allgatherv(f64(self.primary['dec']), self.group)
-		err, _ = allgatherv(f64(numpy.broadcast_to(numpy.asarray(self.primary['error'], dtype=float), numpy.shape(self.primary['ra']))), self.group)
+		ra, counts = allgatherv(f64(self.primary['ra']), self.group, self.comm)
+		dec, _ = allgatherv(f64(self.primary['dec']), self.group, self.comm)
+		err, _ = allgatherv(f64(numpy.broadcast_to(numpy.asarray(self.primary['error'], dtype=float), numpy.shape(self.primary['ra']))), self.group, self.comm)
 		self.gathered_bytes = 24 * int(ra.shape[0])
 		self.primary_all = dict(name=self.primary['name'], ra=ra, dec=dec, error=err, area=self.primary['area'])
 		self.bounds = numpy.concatenate([[0], numpy.cumsum(counts)]).astype(numpy.int64)
@@ -477,7 +498,11 @@ class SecondarySplitMatch(object):
 	# -- per step ------------------------------------------------------------------------
 	def _exchange(self):
 		dist = _dist()
-		if self.world == 1:
+		if self.comm is not None:
+			# the library's own RCCL group of send / recv pairs on the pipeline's stream (nwayhip_comm_exchange): no host
+			# round trip between the two halves
+			self.comm.exchange(self.export, self.imported)
+		elif self.world == 1:
 			self.imported.copy_(self.export)
 		elif dist.get_backend(self.group) == 'nccl':
 			dist.all_to_all_single(self.imported, self.export, group=self.group)

@@ -162,7 +162,25 @@ def rccl_worker(rank, world, port, outfile):
 		sm = distributed.ShardedMatch(tabs[0], [tabs[1]], 10., 0.9, device=dev)
 		sm.step()
 		rows = sm.total_rows()
-		np.savez(outfile, ok=ok, rows=rows, backend=dist.get_backend())
+		# the same exchanges through the library's OWN RCCL calls (nwayhip_comm_*: comm='rccl'), both engines
+		comm = distributed.make_comm(dev)
+		col = torch.arange(1000, dtype=torch.float64, device=dev) * 0.5
+		got_col = comm.allgatherv(col, [1000])
+		blocks = torch.arange(4096, dtype=torch.uint8, device=dev)
+		back = torch.zeros_like(blocks)
+		comm.exchange(blocks, back)
+		torch.cuda.synchronize(dev)
+		ok = ok and torch.equal(got_col, col) and torch.equal(back, blocks)
+		sm2 = distributed.ShardedMatch(tabs[0], [tabs[1]], 10., 0.9, device=dev, comm=comm)
+		sm2.step()
+		sp = distributed.SecondarySplitMatch(tabs[0], [tabs[1]], 10., 0.9, device=dev, comm=comm)
+		for _ in range(3):
+			sp.step()
+		t_split = sp.local_table()
+		t_shard = sm.local_table()
+		same = all(np.array_equal(t_split[key], t_shard[key], equal_nan=True) for key in t_shard)
+		np.savez(outfile, ok=ok, rows=rows, backend=dist.get_backend(), rows_rccl=sm2.total_rows(), rows_split=sp.total_rows(), same=same)
+		comm.close()
 	finally:
 		dist.destroy_process_group()
 
@@ -178,17 +196,20 @@ def test_rccl_is_there_and_carries_the_engines_collectives(tmp_path):
 	assert bool(got['ok']) and str(got['backend']) == 'nccl'
 	want = nw.nway_match(catalogues(2, False), 10., 0.9, logger=nw.NullOutputLogger())
 	assert int(got['rows']) == len(want)
+	# through nwayhip_comm_* (RCCL behind the C ABI): the same rows from both engines, the split mode's table equal to the sharded one
+	assert int(got['rows_rccl']) == len(want) and int(got['rows_split']) == len(want) and bool(got['same'])
 
 
-@pytest.mark.parametrize('scaling', ['weak', 'strong'])
-def test_bench_one_rank_through_rccl(scaling):
+@pytest.mark.parametrize('scaling,comm', [('weak', 'torch'), ('strong', 'torch'), ('weak', 'rccl'), ('strong', 'rccl')])
+def test_bench_one_rank_through_rccl(scaling, comm):
 	"""bench.py's N > 1 code -- engines, barriers, the MAX over ranks -- with ONE rank on the real backend ("nccl" = RCCL):
 	NWAY_BENCH_FORCE_DIST=1 (the driver's 2 / 4 / 8-GPU runs take the same lines with more ranks)"""
 	env = dict(os.environ, NWAY_BENCH_FORCE_DIST='1', HSA_ENABLE_IPC_MODE_LEGACY='0', MASTER_PORT=str(free_port()))
 	cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '5', '--warmup', '2', '--prewarm', '3', '--n-primary', '20000',
-		'--n-secondary', '2000000', '--scaling', scaling, '--cpu-sample', '0']
+		'--n-secondary', '2000000', '--scaling', scaling, '--cpu-sample', '0', '--comm', comm]
 	res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, timeout=600, env=env, cwd=ROOT)
 	assert res.returncode == 0, res.stderr[-3000:]
 	out = json.loads([l for l in res.stdout.splitlines() if l.startswith('{')][-1])
 	assert out['n_gpus'] == 1 and out['scaling'] == scaling and 20000 * 1.7 < out['config']['rows_per_step'] < 20000 * 1.9
+	assert out['config']['exchanges'].startswith('nwayhip_comm' if comm == 'rccl' else 'torch')
 	assert out['config']['parallelism'].startswith('secondary-stream' if scaling == 'strong' else 'primary-row')
