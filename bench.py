@@ -442,6 +442,7 @@ def main():
 				rows_per_step=rows_per_step, distance_tests_per_step_rank0=int(st[_hip.ST_TESTS]),
 				survivors_per_step_rank0=int(st[_hip.ST_SURVIVORS]), registrations_rank0=int(st[_hip.ST_REGISTRATIONS]),
 				parallelism=('secondary-stream slices x%d + candidate routing' % world) if strong else ('primary-row shards x%d' % world),
+				exchanges=(None if engine is None else ('nwayhip_comm_* (RCCL behind the C ABI)' if args.comm == 'rccl' else 'torch.distributed')),
 				streams=len(plans), secondary_buffers=(len(sec_copies) if engine is None else 1), prewarm_steps=max(args.prewarm, 0),
 				setup_exchange=(None if engine is None else dict(seconds=engine.setup_seconds, bytes=engine.gathered_bytes,
 					note='one-time exchange at set-up (RCCL), outside the timed steps'))),
