@@ -20,7 +20,7 @@ def short(name):
 
 
 lines = []
-stats = glob.glob(os.path.join(src, 'stats', '*', '*kernel_stats.csv'))
+stats = sorted(glob.glob(os.path.join(src, 'stats', '*', '*kernel_stats.csv')), key=os.path.getmtime, reverse=True)  # (the newest run of the directory)
 kernel_avg = {}
 if stats:
 	lines.append('# rocprofv3 --kernel-trace --stats -- python bench.py --steps 20 --warmup 3 --cpu-sample 0')
@@ -32,7 +32,7 @@ if stats:
 			float(r['AverageNs']) / 1e3, float(r['MaxNs']) / 1e3, r['Percentage']))
 counters = {}
 for which in ('fetch', 'write'):
-	files = glob.glob(os.path.join(src, which, '*', '*counter_collection.csv'))
+	files = sorted(glob.glob(os.path.join(src, which, '*', '*counter_collection.csv')), key=os.path.getmtime, reverse=True)
 	if not files:
 		continue
 	per_kernel = {}
