@@ -833,3 +833,22 @@ def test_sparse_tails_with_more_rows_than_their_staging_area(nw, k):
 	for key in out[0]:
 		np.testing.assert_array_equal(out[0][key], out[-1][key], err_msg=key)
 	oracle_vs_hip(nw, tabs, 10., 0.9, names, oracle=orc_c)
+
+
+def test_read_probe_sums_both_columns(nw):
+	"""nwayhip_read_probe (bench.py's measured read ceiling): every element of both columns is read exactly once --
+	the per-workgroup partial sums add up to the sum of the columns, for sizes that do not divide into the tiles"""
+	import ctypes
+	import torch
+	from nway_amd import _hip
+	lib = _hip.load()
+	dev = torch.device('cuda', 0)
+	for n in (2, 4098, 1000001 * 2):
+		a = torch.arange(n, dtype=torch.float64, device=dev) % 1000
+		b = torch.ones(n, dtype=torch.float64, device=dev) * 0.5
+		for blocks in (1, 7, 256):
+			out = torch.zeros(blocks, dtype=torch.float64, device=dev)
+			_hip.check(lib.nwayhip_read_probe(_hip.ptr(a), _hip.ptr(b), n, _hip.ptr(out), blocks, _hip.current_stream_ptr(dev)))
+			assert float(out.sum().item()) == float(a.sum().item()) + 0.5 * n, (n, blocks)
+	with pytest.raises(_hip.NwayHipError):
+		_hip.check(lib.nwayhip_read_probe(None, _hip.ptr(b), 10, _hip.ptr(out), 1, None))
