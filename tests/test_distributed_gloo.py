@@ -68,7 +68,7 @@ def worker(rank, world, port, outfile):
 		dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('world', [2])
+@pytest.mark.parametrize('world', [2, 3])
 def test_sharded_equals_unsharded(tmp_path, world):
 	import nway_oracle as orc
 	outfile = str(tmp_path / 'gathered.npz')
