@@ -364,6 +364,23 @@ def main():
 			note='host arrays -> HBM before the timed region (page-locked in place for the copy engine), table -> host after it; never part of `value`')
 	else:
 		step = engine.step
+		n_sec_copies = 1
+		if not strong and engine.plan is not None:
+			# as on one GPU: the passes alternate over distinct device copies of the secondary catalogue, so that no pass
+			# finds its 160 MB stream in the 256 MiB Infinity Cache (every rank holds the whole catalogue in this mode)
+			def clone(c):
+				cp = _hip.DeviceCatalogue.__new__(_hip.DeviceCatalogue)
+				cp.ra, cp.dec = c.ra.clone(), c.dec.clone()
+				cp.sigma = None if c.sigma is None else c.sigma.clone()
+				cp.sigma_const, cp.n = c.sigma_const, c.n
+				return cp
+			copies = [engine.cats] + [[engine.cats[0]] + [clone(c) for c in engine.cats[1:]] for _ in range(max(args.sec_buffers, 1) - 1)]
+			n_sec_copies = len(copies)
+			turn = [0]
+
+			def step():
+				engine.step(copies[turn[0] % len(copies)])
+				turn[0] += 1
 		read_status = engine.read_status
 		engine.step()
 		rows_per_step = engine.total_rows()
@@ -443,7 +460,7 @@ def main():
 				survivors_per_step_rank0=int(st[_hip.ST_SURVIVORS]), registrations_rank0=int(st[_hip.ST_REGISTRATIONS]),
 				parallelism=('secondary-stream slices x%d + candidate routing' % world) if strong else ('primary-row shards x%d' % world),
 				exchanges=(None if engine is None else ('nwayhip_comm_* (RCCL behind the C ABI)' if args.comm == 'rccl' else 'torch.distributed')),
-				streams=len(plans), secondary_buffers=(len(sec_copies) if engine is None else 1), prewarm_steps=max(args.prewarm, 0),
+				streams=len(plans), secondary_buffers=(len(sec_copies) if engine is None else n_sec_copies), prewarm_steps=max(args.prewarm, 0),
 				setup_exchange=(None if engine is None else dict(seconds=engine.setup_seconds, bytes=engine.gathered_bytes,
 					note='one-time exchange at set-up (RCCL), outside the timed steps'))),
 			roofline=dict(bound='hbm', kernel='k_sweep', achieved=achieved, peak=HBM_PEAK_GBS, unit='GB/s',

@@ -230,10 +230,11 @@ class ShardedMatch(object):
 		self.plan, self.status = _hip.run_plan(sizes, self.params, self.cats, cap_pairs, cap_rows, self.device, lean=True)
 
 	# -- per batch -----------------------------------------------------------------------
-	def step(self):
-		"""one pass of the hot path over this rank's primary shard (no collective)"""
+	def step(self, cats=None):
+		"""one pass of the hot path over this rank's primary shard (no collective).  cats: other device copies of the same
+		catalogues (bench.py alternates over copies of the secondaries so that no pass finds its stream in the Infinity Cache)"""
 		if not self.empty:
-			self.plan.enqueue(self.cats)
+			self.plan.enqueue(self.cats if cats is None else cats)
 
 	def read_status(self):
 		return self.status if self.plan is None else self.plan.read_status()
