@@ -59,6 +59,8 @@ extern "C" {
 #define NWAYHIP_FLAG_LOOKBACK 16         /* the single-pass scan timed out: repeat with link_slots = -1 */
 #define NWAYHIP_FLAG_BARRIER 32          /* the sweep launch that also registers the primaries did not get the GPU to itself
                                             (its workgroups wait for each other): repeat without NWAYHIP_ENABLE_FUSED_FRONT */
+#define NWAYHIP_FLAG_QUAD_DEEP 64        /* k = 3 tail with four lanes per primary (k_tail3q): a primary has three or more candidates in a
+                                            catalogue: repeat with NWAYHIP_DISABLE_QUAD3 */
 
 typedef struct nwayhip_catalogue {
 	const double* ra;                    /* degrees */
@@ -116,11 +118,13 @@ typedef struct nwayhip_match_params {
 #define NWAYHIP_DISABLE_HYBRID 2         /* dense k >= 3: the general path instead of sparse front + general back end */
 #define NWAYHIP_DISABLE_FUSED_CORRECTION 4 /* NWAYHIP_CORRECTION_CLI: k_correct behind the general back end instead of the fused tails */
 #define NWAYHIP_DISABLE_ONE_SWEEP 8      /* sparse k >= 3: one sweep launch per secondary catalogue instead of one for all */
+#define NWAYHIP_DISABLE_QUAD3 16         /* sparse k = 3: k_tailk<3> (one lane per primary) instead of k_tail3q (four) */
 #define NWAYHIP_ENABLE_FUSED_FRONT 1     /* the registration of the primaries INSIDE the sweep launch (front.inc: k_sweep<.., FUSED>;
                                             sparse front with the bitmap in LDS): one launch and one kernel boundary fewer,
                                             the first tiles hashed across a grid barrier.  Measured no faster than the two
                                             launches and in need of the whole GPU (NWAYHIP_FLAG_BARRIER):
                                             off unless asked for */
+#define NWAYHIP_ENABLE_QUAD3 2           /* sparse k = 3: k_tail3q whatever the density of chance neighbours (default: below 0.02 per primary) */
 
 /* Output table, SoA, `capacity` rows allocated by the caller.  Columns follow
  * __init__.py:133-177,100-111,405-418 / SURVEY.md appendix C. */
@@ -221,6 +225,7 @@ int32_t nwayhip_plan_path(const nwayhip_plan* plan);
 #define NWAYHIP_TAIL_SPARSEK 3           /* k_tailk<K> */
 #define NWAYHIP_TAIL_DENSE3 4            /* k_taild_test + k_taild3_count + scan + k_taild3_rows */
 #define NWAYHIP_TAIL_HYBRID 5            /* slots -> lists, then the general back end */
+#define NWAYHIP_TAIL_QUAD3 6             /* k_tail3q: k = 3, four lanes per primary */
 int nwayhip_plan_describe(const nwayhip_plan* plan, int32_t* h_out);
 /* 1 if the plan can run the secondary-split mode below (sparse front with the tails
  * NWAYHIP_TAIL_SPARSE2 / NWAYHIP_TAIL_DENSE2 / NWAYHIP_TAIL_SPARSEK), else 0 */

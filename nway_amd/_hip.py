@@ -21,20 +21,20 @@ ST_ROWS, ST_FLAGS, ST_REGISTRATIONS, ST_TESTS, ST_REGION_NEED, ST_SLOT_NEED = 0,
 LINK_SLOTS_CAP = 128
 LINK_SLOTS_MAX_FUSED = 8  # most slots of the one-launch fused tails (sparse.inc: LINK_SLOTS_MAX)
 ST_SURVIVORS, ST_PAIRS, ST_NOTFLAT = 8, 16, 24
-FLAG_PAIR_OVERFLOW, FLAG_ROW_OVERFLOW, FLAG_REG_OVERFLOW, FLAG_SLOT_OVERFLOW, FLAG_LOOKBACK, FLAG_BARRIER = 1, 2, 4, 8, 16, 32
+FLAG_PAIR_OVERFLOW, FLAG_ROW_OVERFLOW, FLAG_REG_OVERFLOW, FLAG_SLOT_OVERFLOW, FLAG_LOOKBACK, FLAG_BARRIER, FLAG_QUAD_DEEP = 1, 2, 4, 8, 16, 32, 64
 PATH_GENERAL, PATH_SPARSE, PATH_HYBRID = 0, 1, 2
 SCHEME_FLAT, SCHEME_SPHERE = 0, 1
 STAGES = 8
 STAGE_NAMES = ['register', 'sweep', 'pairs', 'lists', 'expand', 'rows', 'groups']
 CORRECTION_NONE, CORRECTION_CLI = 0, 1
-DISABLE_DENSE3, DISABLE_HYBRID, DISABLE_FUSED_CORRECTION, DISABLE_ONE_SWEEP = 1, 2, 4, 8
-ENABLE_FUSED_FRONT = 1
+DISABLE_DENSE3, DISABLE_HYBRID, DISABLE_FUSED_CORRECTION, DISABLE_ONE_SWEEP, DISABLE_QUAD3 = 1, 2, 4, 8, 16
+ENABLE_FUSED_FRONT, ENABLE_QUAD3 = 1, 2
 DESC_WORDS = 8
 DESC_NAMES = ['path', 'link_slots', 'direct_log2', 'sweep', 'tail', 'fold_log2', 'one_sweep', 'fused_front']
 SWEEP_GENERAL, SWEEP_LDS, SWEEP_BIG = 0, 1, 2
 SWEEP_NAMES = ['general', 'lds', 'big']
 TAIL_GENERAL, TAIL_SPARSE2, TAIL_DENSE2, TAIL_SPARSEK, TAIL_DENSE3, TAIL_HYBRID = 0, 1, 2, 3, 4, 5
-TAIL_NAMES = ['general', 'sparse2', 'dense2', 'sparsek', 'dense3', 'hybrid']
+TAIL_NAMES = ['general', 'sparse2', 'dense2', 'sparsek', 'dense3', 'hybrid', 'quad3']
 
 
 class NwayHipError(RuntimeError):
@@ -536,6 +536,14 @@ def run_plan(sizes, params, catalogues, cap_pairs, cap_rows, device, max_retries
 			spend('path')
 			params.enable = int(params.enable) & ~ENABLE_FUSED_FRONT
 			continue
+		if flags & FLAG_QUAD_DEEP:
+			# a primary with three or more candidates in one catalogue: the 3-way tail with four lanes per primary
+			# leaves those to the one that walks them (csrc/tail3q.inc)
+			params.disable = int(params.disable) | DISABLE_QUAD3
+			flags &= ~FLAG_QUAD_DEEP
+			if flags == 0 or flags == FLAG_ROW_OVERFLOW:  # (the rows of those primaries were not counted)
+				spend('path')
+				continue
 		need = int(st[ST_SLOT_NEED])
 		if flags & FLAG_SLOT_OVERFLOW and not flags & (FLAG_LOOKBACK | FLAG_REG_OVERFLOW) and 0 < need <= LINK_SLOTS_CAP and tries['slots'] < 2:
 			# a primary with more candidates than the slots sized for the mean density (a clustered

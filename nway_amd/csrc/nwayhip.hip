@@ -51,6 +51,7 @@
 #include "tail2.inc"
 #include "taild.inc"
 #include "tailk.inc"
+#include "tail3q.inc"
 #include "taild3.inc"
 #include "elementwise.inc"
 #include "api.inc"

@@ -477,6 +477,9 @@ class SecondarySplitMatch(object):
 			# the plan and what points into its buffers go before anything is raised or retried
 			self._drop_plan()
 			fatal = flags_any & (_hip.FLAG_LOOKBACK | _hip.FLAG_REG_OVERFLOW)
+			if flags_any & _hip.FLAG_QUAD_DEEP:
+				# (3-way: a primary with three candidates in a catalogue; the tail that walks them from now on, csrc/tail3q.inc)
+				self.params.disable = int(self.params.disable) | _hip.DISABLE_QUAD3
 			if flags_any & _hip.FLAG_SLOT_OVERFLOW and not fatal and 0 < slot_need <= _hip.LINK_SLOTS_MAX_FUSED and slot_retries < 2:
 				# a clustered primary: once or twice more with the slots the run counted (as run_plan does)
 				slot_retries += 1

@@ -633,7 +633,10 @@ def test_sparse_fast_path_three_way(nw):
 	for slots in (0, 2, -1):
 		res = nw.run_match([a, b, c], 10., 0.9, link_slots=slots, logger=nw.NullOutputLogger())
 		assert int(res.status[_hip.ST_FLAGS]) == 0
-		assert res.plan.sparse == (slots != -1) and res.plan.attempts == (2 if slots == 2 else 1)
+		# (default slots: the tail with four lanes per primary meets primary 11's four candidates and hands the run to the walk, NWAYHIP_FLAG_QUAD_DEEP)
+		assert res.plan.sparse == (slots != -1) and res.plan.attempts == (1 if slots == -1 else 2)
+		if slots == 0:
+			assert res.plan.description['tail'] == 'sparsek'
 		tables[slots] = dict(idx1=res.to_host('idx', 1), idx2=res.to_host('idx', 2), p_i=res.to_host('p_i'),
 			flag=res.to_host('match_flag'), bf=res.to_host('log_bf'), gs=res.plan.cols['group_start'].cpu().numpy())
 		res.plan.close()
