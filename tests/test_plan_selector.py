@@ -143,3 +143,18 @@ def test_environment_is_ignored_without_the_development_guard(monkeypatch):
 	monkeypatch.setenv('NWAYHIP_DIRECT_LOG2', '22')
 	d = describe([100000, 10000000], 0.1)
 	assert (d['link_slots'], d['direct_log2'], d['sweep']) == (8, 20, 'lds')
+
+
+def test_four_lanes_per_primary_of_a_sparse_three_way_field():
+	"""k = 3, fewer than 0.02 chance neighbours per primary: k_tail3q (a primary with three candidates in a catalogue
+	sends the run back to k_tailk, which must stay rare); the caller's switches either way; never for other k"""
+	from nway_amd import _hip
+	n = [100000, 1000000, 1000000]
+	below, above = describe(n, 0.019), describe(n, 0.021)
+	assert (below['tail'], below['link_slots'], below['split_capable']) == ('quad3', 8, 1)
+	assert (above['tail'], above['link_slots'], above['split_capable']) == ('sparsek', 8, 1)
+	assert describe(n, 0.3, tuning=dict(enable=_hip.ENABLE_QUAD3))['tail'] == 'quad3'
+	assert describe(n, 0.001, tuning=dict(disable=_hip.DISABLE_QUAD3))['tail'] == 'sparsek'
+	assert describe(n, 0.001, link_slots=1)['tail'] == 'sparsek'   # (its lanes read two slots of every primary)
+	assert describe(n, 0.001, correction=_hip.CORRECTION_CLI)['tail'] == 'quad3'
+	assert describe(n[:2], 0.001)['tail'] == 'sparse2' and describe(n + [1000000], 0.001)['tail'] == 'sparsek'
