@@ -193,8 +193,9 @@ def _upload_large(a, out):
 	rt = t.cuda.cudart()
 	registered = False
 	try:
-		rc = rt.cudaHostRegister(a.ctypes.data, a.nbytes, 0)
-		registered = int(rc) == 0
+		if os.environ.get('NWAY_UPLOAD', '') != 'staged':  # (development: the staged path on a stack that registers)
+			rc = rt.cudaHostRegister(a.ctypes.data, a.nbytes, 0)
+			registered = int(rc) == 0
 	except Exception:
 		registered = False
 	if registered:
