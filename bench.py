@@ -356,9 +356,9 @@ def main():
 		t0 = time.perf_counter()
 		d2h_bytes = 0
 		for name in ('sep_max', 'log_bf', 'dist_post', 'p_single', 'p_any', 'p_i', 'ncat', 'match_flag'):
-			d2h_bytes += plan.cols[name][:rows_per_step].cpu().numpy().nbytes
+			d2h_bytes += _hip.to_host(plan.cols[name][:rows_per_step]).nbytes
 		for col in plan.cols['idx'] + plan.cols['sep']:
-			d2h_bytes += col[:rows_per_step].cpu().numpy().nbytes
+			d2h_bytes += _hip.to_host(col[:rows_per_step]).nbytes
 		d2h_s = time.perf_counter() - t0
 		io = dict(h2d_ms=h2d_s * 1e3, h2d_first_ms=h2d_first_s * 1e3, h2d_bytes=int(h2d_bytes), h2d_mode=_hip.upload_mode['last'], d2h_ms=d2h_s * 1e3, d2h_bytes=int(d2h_bytes),
 			note='host arrays -> HBM before the timed region (page-locked in place for the copy engine), table -> host after it; never part of `value`')

@@ -129,7 +129,7 @@ class MatchResult(object):
 		return col[:self.nrows]
 
 	def to_host(self, name, index=None):
-		return self.column(name, index).cpu().numpy()
+		return _hip.to_host(self.column(name, index))
 
 
 def run_match(match_tables, match_radius, prior_completeness=1.0, prob_ratio_secondary=0.5,

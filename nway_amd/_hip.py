@@ -225,6 +225,28 @@ def _upload_large(a, out):
 	return out
 
 
+_download_stage = {}
+
+
+def to_host(tensor):
+	"""device tensor -> numpy array of its own.  Large columns come down through a page-locked staging buffer kept for the
+	purpose (the runtime otherwise page-locks the fresh destination on the fly for every copy); NWAY_DOWNLOAD=direct: the
+	runtime's own path"""
+	t = torch()
+	nbytes = tensor.numel() * tensor.element_size()
+	if not tensor.is_cuda or nbytes < (64 << 10) or os.environ.get('NWAY_DOWNLOAD', '') == 'direct':
+		return tensor.cpu().numpy()
+	src = tensor.contiguous()
+	stage = _download_stage.get(src.dtype)
+	if stage is None or stage.numel() < src.numel():
+		stage = t.empty(max(src.numel(), (4 << 20) // src.element_size()), dtype=src.dtype, pin_memory=True)
+		_download_stage[src.dtype] = stage
+	view = stage[:src.numel()]
+	view.copy_(src.reshape(-1), non_blocking=True)
+	t.cuda.current_stream(src.device).synchronize()
+	return view.numpy().reshape(tuple(src.shape)).copy()
+
+
 def to_device(array, device, dtype=None):
 	"""numpy array or torch tensor -> contiguous device tensor (float64 by default)"""
 	t = torch()

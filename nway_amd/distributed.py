@@ -280,14 +280,14 @@ class ShardedMatch(object):
 			names = [self.primary['name']] + [f['name'] for f in self.full_secondaries]
 			t = {}
 			for c, nme in enumerate(names):
-				t[nme] = self.plan.cols['idx'][c][:m].cpu().numpy().astype(numpy.int64)
+				t[nme] = _hip.to_host(self.plan.cols['idx'][c][:m]).astype(numpy.int64)
 			for p, (i, j) in enumerate(_hip.pair_columns(len(names))):
-				t['Separation_%s_%s' % (names[i], names[j])] = self.plan.cols['sep'][p][:m].cpu().numpy()
+				t['Separation_%s_%s' % (names[i], names[j])] = _hip.to_host(self.plan.cols['sep'][p][:m])
 			for src, dst in (('sep_max', 'Separation_max'), ('log_bf', 'dist_bayesfactor_uncorrected'), ('log_bf_corrected', 'dist_bayesfactor'),
 					('dist_post', 'dist_post'), ('p_single', 'p_single'), ('p_any', 'prob_has_match'), ('p_i', 'prob_this_match')):
-				t[dst] = self.plan.cols[src][:m].cpu().numpy()
-			t['ncat'] = self.plan.cols['ncat'][:m].cpu().numpy().astype(numpy.int64)
-			t['match_flag'] = self.plan.cols['match_flag'][:m].cpu().numpy().astype(numpy.int64)
+				t[dst] = _hip.to_host(self.plan.cols[src][:m])
+			t['ncat'] = _hip.to_host(self.plan.cols['ncat'][:m]).astype(numpy.int64)
+			t['match_flag'] = _hip.to_host(self.plan.cols['match_flag'][:m]).astype(numpy.int64)
 		pname = self.primary['name']
 		t[pname] = numpy.asarray(t[pname]) + self.primary_offset
 		return t
@@ -561,14 +561,14 @@ class SecondarySplitMatch(object):
 		names = [self.primary['name']] + [s['name'] for s in self.secondary_slices]
 		t = {}
 		for c, nme in enumerate(names):
-			t[nme] = self.plan.cols['idx'][c][:m].cpu().numpy().astype(numpy.int64)
+			t[nme] = _hip.to_host(self.plan.cols['idx'][c][:m]).astype(numpy.int64)
 		for p, (i, j) in enumerate(_hip.pair_columns(len(names))):
-			t['Separation_%s_%s' % (names[i], names[j])] = self.plan.cols['sep'][p][:m].cpu().numpy()
+			t['Separation_%s_%s' % (names[i], names[j])] = _hip.to_host(self.plan.cols['sep'][p][:m])
 		for src, dst in (('sep_max', 'Separation_max'), ('log_bf', 'dist_bayesfactor_uncorrected'), ('log_bf_corrected', 'dist_bayesfactor'),
 				('dist_post', 'dist_post'), ('p_single', 'p_single'), ('p_any', 'prob_has_match'), ('p_i', 'prob_this_match')):
-			t[dst] = self.plan.cols[src][:m].cpu().numpy()
-		t['ncat'] = self.plan.cols['ncat'][:m].cpu().numpy().astype(numpy.int64)
-		t['match_flag'] = self.plan.cols['match_flag'][:m].cpu().numpy().astype(numpy.int64)
+			t[dst] = _hip.to_host(self.plan.cols[src][:m])
+		t['ncat'] = _hip.to_host(self.plan.cols['ncat'][:m]).astype(numpy.int64)
+		t['match_flag'] = _hip.to_host(self.plan.cols['match_flag'][:m]).astype(numpy.int64)
 		return t
 
 	def gather_table(self, dst=0):
