@@ -31,7 +31,7 @@ def _on_device(arrays):
 
 
 def _finish(out, shape):
-	res = out.cpu().numpy().reshape(shape)
+	res = _hip.to_host(out).reshape(shape)
 	return res if shape else float(res)
 
 

@@ -295,7 +295,7 @@ def main(argv=None):
 			_hip.check(lib.nwayhip_bias_lookup(res.nrows, _hip.ptr(res.column('idx', ti)), _hip.ptr(d_mag), len(func.edges),
 				_hip.ptr(d_edges), _hip.ptr(d_ratio), _hip.ptr(total), _hip.ptr(d_bias), _hip.current_stream_ptr(device)))
 			biases.append(col)
-			columns.append(('bias_%s' % col, 'E', d_bias.cpu().numpy()))
+			columns.append(('bias_%s' % col, 'E', _hip.to_host(d_bias)))
 		print()
 		print('Computing final probabilities ...')
 		from . import magpriors

@@ -37,6 +37,46 @@
 
 #include "nwayhip.h"
 
+#ifdef NWAYHIP_DEVBUILD
+// development builds only: with NWAYHIP_LAUNCH_LOG=<file> every launch is followed by a synchronisation and a pause, and the file
+// always names the launch in flight and the one before it -- what a device fault that the runtime reports without a kernel
+// name (a posted store outside its buffer) is traced with (tools/dev/fault_loop.sh)
+#include <fcntl.h>
+#include <unistd.h>
+static int dev_launch_fd() {
+	static int fd = -2;
+	if (fd == -2) {
+		const char* e = getenv("NWAYHIP_LAUNCH_LOG");
+		fd = (e && *e) ? open(e, O_WRONLY | O_CREAT | O_TRUNC, 0644) : -1;
+	}
+	return fd;
+}
+static void dev_launch_note(const char* name, int state, int line) {
+	static char prev[200] = "";
+	static long long count = 0;
+	const int fd = dev_launch_fd();
+	if (fd < 0) return;
+	char buf[512];
+	memset(buf, ' ', sizeof(buf));
+	const int n = snprintf(buf, sizeof(buf), "#%lld %s %s (plan.inc:%d) | before: %s", ++count, state ? "finished" : "IN FLIGHT", name, line, prev);
+	if (n > 0 && n < (int)sizeof(buf)) buf[n] = ' ';
+	buf[sizeof(buf) - 1] = '\n';
+	if (pwrite(fd, buf, sizeof(buf), 0) < 0) return;
+	if (state) snprintf(prev, sizeof(prev), "%s:%d", name, line);
+}
+#undef hipLaunchKernelGGL
+#define hipLaunchKernelGGL(kernelName, numBlocks, numThreads, memPerBlock, streamId, ...)                    \
+	do {                                                                                                  \
+		dev_launch_note(#kernelName, 0, __LINE__);                                                        \
+		hipLaunchKernelGGLInternal((kernelName), (numBlocks), (numThreads), (memPerBlock), (streamId), __VA_ARGS__); \
+		if (dev_launch_fd() >= 0) {                                                                       \
+			(void)hipStreamSynchronize(streamId);                                                         \
+			usleep(1500);                                                                                 \
+			dev_launch_note(#kernelName, 1, __LINE__);                                                    \
+		}                                                                                                 \
+	} while (0)
+#endif
+
 #pragma clang fp contract(off)
 
 #include "common.inc"

@@ -36,7 +36,7 @@ def offsets(a_ra, a_dec, b_ra, b_dec):
 	d_lat = t.empty(n, dtype=t.float64, device=device)
 	_hip.check(_hip.load().nwayhip_offsets(_hip.ptr(dev[0]), _hip.ptr(dev[1]), _hip.ptr(dev[2]), _hip.ptr(dev[3]), n,
 		_hip.ptr(d_lon), _hip.ptr(d_lat), _hip.current_stream_ptr(device)))
-	lon, lat = d_lon.cpu().numpy().reshape(shape), d_lat.cpu().numpy().reshape(shape)
+	lon, lat = _hip.to_host(d_lon).reshape(shape), _hip.to_host(d_lat).reshape(shape)
 	return (lon, lat) if shape else (float(lon), float(lat))
 
 

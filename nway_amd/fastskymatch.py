@@ -35,7 +35,7 @@ def dist(apos, bpos):
 		out = t.empty(n, dtype=t.float32, device=device)
 		_hip.check(_hip.load().nwayhip_dist_f32(_hip.ptr(dev[0]), _hip.ptr(dev[1]), _hip.ptr(dev[2]), _hip.ptr(dev[3]), n,
 			_hip.ptr(out), _hip.current_stream_ptr(device)))
-		return out.cpu().numpy().reshape(shape)
+		return _hip.to_host(out).reshape(shape)
 	arrs = numpy.broadcast_arrays(*[numpy.asarray(x, dtype=float) for x in (a_ra, a_dec, b_ra, b_dec)])
 	shape = arrs[0].shape
 	dev = [_hip.to_device(numpy.ascontiguousarray(a).reshape(-1), device) for a in arrs]
@@ -43,7 +43,7 @@ def dist(apos, bpos):
 	out = t.empty(n, dtype=t.float64, device=device)
 	_hip.check(_hip.load().nwayhip_dist(_hip.ptr(dev[0]), _hip.ptr(dev[1]), _hip.ptr(dev[2]), _hip.ptr(dev[3]), n,
 		_hip.ptr(out), _hip.current_stream_ptr(device)))
-	res = out.cpu().numpy().reshape(shape)
+	res = _hip.to_host(out).reshape(shape)
 	return res if shape else float(res)
 
 

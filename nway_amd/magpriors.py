@@ -103,7 +103,7 @@ def apply_magnitude_biasing(match_tables, table, res, mag_include_radius, mag_ex
 			d_bias = t.empty(nrows, dtype=t.float64, device=device)
 			_hip.check(lib.nwayhip_bias_lookup(nrows, _hip.ptr(res.column('idx', i)), _hip.ptr(d_mag), len(func.edges),
 				_hip.ptr(d_edges), _hip.ptr(d_ratio), _hip.ptr(total), _hip.ptr(d_bias), _hip.current_stream_ptr(device)))
-			bias_columns['bias_%s' % col] = d_bias.cpu().numpy()
+			bias_columns['bias_%s' % col] = _hip.to_host(d_bias)
 	table = table.assign(**bias_columns)
 	return table, total
 
