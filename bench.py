@@ -197,16 +197,16 @@ def table_check(plan, names, cpu_table):
 		return out
 	ok = True
 	for c, nme in enumerate(names):
-		same = bool(np.array_equal(plan.cols['idx'][c][:m].cpu().numpy().astype(np.int64), cpu_table[nme]))
+		same = bool(np.array_equal(_hip.to_host(plan.cols['idx'][c][:m]).astype(np.int64), cpu_table[nme]))
 		out['idx_%s_equal' % nme] = same
 		ok &= same
-	flag = plan.cols['match_flag'][:m].cpu().numpy().astype(np.int64)
+	flag = _hip.to_host(plan.cols['match_flag'][:m]).astype(np.int64)
 	out['match_flag_equal'] = bool(np.array_equal(flag, cpu_table['match_flag']))
 	out['match_flag_histogram'] = [int(x) for x in np.bincount(flag, minlength=3)]
 	ok &= out['match_flag_equal']
 	worst = 0.0
 	for src, dst in (('log_bf', 'dist_bayesfactor'), ('dist_post', 'dist_post'), ('p_single', 'p_single'), ('p_any', 'prob_has_match'), ('p_i', 'prob_this_match')):
-		got, want = plan.cols[src][:m].cpu().numpy(), cpu_table[dst]
+		got, want = _hip.to_host(plan.cols[src][:m]), cpu_table[dst]
 		rel = np.abs(got - want) / np.maximum(np.abs(want), 1e-12)
 		rel = np.where(np.abs(got - want) <= 1e-12, 0.0, rel)
 		worst = max(worst, float(np.nanmax(rel)) if m else 0.0)

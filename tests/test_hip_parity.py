@@ -605,7 +605,7 @@ def test_sparse_fast_path_and_its_fallback(nw):
 		if slots == 2:
 			assert res.plan.attempts == 2 and res.plan.link_slots == 6 and res.plan.sparse  # five candidates counted, six slots the second time
 		tables[slots] = dict(idx1=res.to_host('idx', 1), p_i=res.to_host('p_i'), p_any=res.to_host('p_any'), flag=res.to_host('match_flag'),
-			bf=res.to_host('log_bf'), gs=res.plan.cols['group_start'].cpu().numpy())
+			bf=res.to_host('log_bf'), gs=_hip.to_host(res.plan.cols['group_start']))
 		res.plan.close()
 	assert (tables[0]['idx1'] >= 0).sum() > 50000
 	for key in tables[0]:
@@ -638,7 +638,7 @@ def test_sparse_fast_path_three_way(nw):
 		if slots == 0:
 			assert res.plan.description['tail'] == 'sparsek'
 		tables[slots] = dict(idx1=res.to_host('idx', 1), idx2=res.to_host('idx', 2), p_i=res.to_host('p_i'),
-			flag=res.to_host('match_flag'), bf=res.to_host('log_bf'), gs=res.plan.cols['group_start'].cpu().numpy())
+			flag=res.to_host('match_flag'), bf=res.to_host('log_bf'), gs=_hip.to_host(res.plan.cols['group_start']))
 		res.plan.close()
 	assert (tables[0]['idx2'] >= 0).sum() > 15000
 	for key in tables[0]:
@@ -663,8 +663,8 @@ def test_repeated_runs_of_one_plan(nw, k, slots):
 		t_['dec'][:m] = np.clip(a['dec'][:m] + rng.normal(0, 1, m) / 3600., -90, 90)
 	tabs = [a, b, c][:k]
 	res = nw.run_match(tabs, 10., 0.9, link_slots=slots, logger=nw.NullOutputLogger())
-	snap = lambda: dict(status=res.plan.read_status().copy(), idx=res.plan.cols['idx'][k - 1][:res.nrows].cpu().numpy().copy(),
-		p_i=res.plan.cols['p_i'][:res.nrows].cpu().numpy().copy(), flag=res.plan.cols['match_flag'][:res.nrows].cpu().numpy().copy())
+	snap = lambda: dict(status=res.plan.read_status().copy(), idx=_hip.to_host(res.plan.cols['idx'][k - 1][:res.nrows]),
+		p_i=_hip.to_host(res.plan.cols['p_i'][:res.nrows]), flag=_hip.to_host(res.plan.cols['match_flag'][:res.nrows]))
 	first = snap()
 	assert first['status'][_hip.ST_FLAGS] == 0 and first['status'][_hip.ST_ROWS] == res.nrows
 	cats = [_hip.DeviceCatalogue(t['ra'], t['dec'], np.asarray(t['error'], dtype=float), res.plan.device) for t in tabs]
@@ -700,8 +700,8 @@ def test_one_plan_many_batches(nw, k, slots):
 			ra = (batches[0]['ra'] + 2.0 / 3600.) % 360
 			dec = batches[0]['dec']
 		batches.append(cat('A', ra, dec, rng.uniform(0.5, 2, n0), 41252.96))
-	snap = lambda r: dict(rows=int(r.plan.read_status()[_hip.ST_ROWS]), idx=r.plan.cols['idx'][k - 1][:r.nrows].cpu().numpy().copy(),
-		p_i=r.plan.cols['p_i'][:r.nrows].cpu().numpy().copy(), flag=r.plan.cols['match_flag'][:r.nrows].cpu().numpy().copy())
+	snap = lambda r: dict(rows=int(r.plan.read_status()[_hip.ST_ROWS]), idx=_hip.to_host(r.plan.cols['idx'][k - 1][:r.nrows]),
+		p_i=_hip.to_host(r.plan.cols['p_i'][:r.nrows]), flag=_hip.to_host(r.plan.cols['match_flag'][:r.nrows]))
 	fresh = []
 	for bt in batches:
 		r = nw.run_match([bt] + secs, 10., 0.9, link_slots=slots, logger=nw.NullOutputLogger())
