@@ -292,3 +292,33 @@ def test_dense_three_way_field_with_tens_of_links_per_catalogue():
 	assert len(t['ncat']) > 150 * 400
 	t = both_paths(nw, tabs, 5.0, link_slots=63, correction=1)
 	assert t['_desc']['tail'] == 'dense3'
+
+
+@pytest.mark.parametrize('k', [5, 6])
+def test_many_catalogues_with_two_links_in_several_of_them(k):
+	"""k_tailk<K> for K >= 5 (no register copy of a catalogue's first link, a kernel that spills): primaries with two links in
+	two or more catalogues once got the first link's separation from the second (round 3, found by tools/dev/soak_mid.py with
+	SOAK_KMAX=6) -- mid-size, because the tiny many-catalogue cases of test_hip_fuzz.py never showed it"""
+	import nway_amd as nw
+	from nway_amd import _hip
+	rng = np.random.default_rng(40 + k)
+	sizes = [6000] + [2500] * (k - 1)
+	tabs = patch_tables(rng, sizes, 1.0, [1.0] + [0.3] * (k - 1), frac=0.35)
+	for c in (2, 4, k - 1):  # a second candidate around each of 300 primaries that already have one there
+		at = sizes[c] - 1
+		for i in range(0, 300):
+			tabs[c]['ra'][at] = tabs[0]['ra'][i] + rng.normal(0, 1.5) / 3600.
+			tabs[c]['dec'][at] = tabs[0]['dec'][i] + rng.normal(0, 1.5) / 3600.
+			at -= 1
+	import nway_oracle_c as orc_c
+	names = [x['name'] for x in tabs]
+	t, status = hip_table(nw, tabs, 5.0, 0.9)
+	assert int(status[1]) == 0 and t['_desc']['tail'] == 'sparsek' and t['_path'] == _hip.PATH_SPARSE
+	compare(t, orc_c.nway_match(tabs, 5.0, 0.9, correction='api'), names)
+	g, _ = hip_table(nw, tabs, 5.0, 0.9, link_slots=-1)
+	assert g['_path'] == 0
+	for key in t:  # (the general path sums a group of more than 64 rows by a wave, the walk row by row: equal to rounding)
+		if not key.startswith('_'):
+			np.testing.assert_allclose(t[key], g[key], rtol=1e-12, atol=1e-15, equal_nan=True, err_msg=key)
+	groups = np.bincount(t['T0'].astype(np.int64), minlength=sizes[0])
+	assert (groups >= 18).sum() > 50
