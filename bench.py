@@ -235,7 +235,6 @@ def main():
 	ap.add_argument('--two-pipelines', type=int, default=1, help='also time the steps alternating over two (or this many, if > 2) independent pipelines (reported beside, never as, `value`); 0 = skip')
 	ap.add_argument('--comm', choices=['torch', 'rccl'], default=os.environ.get('NWAY_BENCH_COMM', 'torch'),
 		help='who carries the exchanges of the multi-GPU modes: torch.distributed (default) or the library\'s own RCCL calls behind the C ABI (nwayhip_comm_*)')
-	ap.add_argument('--fused-front', action='store_true', help='development: the registration inside the sweep launch (NWAYHIP_ENABLE_FUSED_FRONT)')
 	ap.add_argument('--streams', type=int, default=int(os.environ.get('NWAY_BENCH_STREAMS', '1')),
 		help='independent pipelines (own workspace, own output table, own HIP stream) the steps alternate over')
 	args = ap.parse_args()
@@ -264,8 +263,7 @@ def main():
 			dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank % ngpu))
 		else:
 			dist.init_process_group(backend)
-	# development: --fused-front runs the registration inside the sweep launch (nwayhip.h: NWAYHIP_ENABLE_FUSED_FRONT)
-	tuning = dict(enable=_hip.ENABLE_FUSED_FRONT) if args.fused_front else None
+	tuning = None
 	if args.gpus != world:
 		if rank == 0:
 			sys.stderr.write('note: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE\n' % (args.gpus, world))
@@ -483,7 +481,7 @@ def main():
 			# of one pass run beside those of the other (the sweeps cannot share a CU: 156 KB of LDS each)
 			params2 = _hip.make_params(2, scheme, args.radius, err, dens, dens_plus, nway_amd._prior_table(dens, dens_plus, comp))
 			second = _hip.MatchPlan(sizes, params2, plan.cap_pairs, plan.cap_rows, device, lean=True)
-			first = plan if not args.fused_front else _hip.MatchPlan(sizes, params2, plan.cap_pairs, plan.cap_rows, device, lean=True)
+			first = plan
 			npipes = max(2, int(args.two_pipelines))
 			more = [_hip.MatchPlan(sizes, params2, plan.cap_pairs, plan.cap_rows, device, lean=True) for _ in range(npipes - 2)]
 			pair, lanes = [first, second] + more, [torch.cuda.Stream(device=device) for _ in range(npipes)]

@@ -25,7 +25,8 @@
 extern "C" {
 #endif
 
-#define NWAYHIP_ABI_VERSION 1
+#define NWAYHIP_ABI_VERSION 2            /* nwayhip_version(); 2 (round 4): nwayhip_log_bf_elliptical gained f32_offsets in round 3 without a
+                                            bump, NWAYHIP_ENABLE_FUSED_FRONT / NWAYHIP_FLAG_BARRIER / NWAYHIP_DESC_FUSED_FRONT are gone */
 #define NWAYHIP_MAXCAT 8                 /* catalogues per match (primary + 7) */
 #define NWAYHIP_MAXPAIR 28               /* MAXCAT*(MAXCAT-1)/2 separation columns */
 
@@ -57,8 +58,7 @@ extern "C" {
 #define NWAYHIP_FLAG_REG_OVERFLOW 4      /* registration table too small */
 #define NWAYHIP_FLAG_SLOT_OVERFLOW 8     /* a primary has more links than link_slots: repeat with more (NWAYHIP_ST_SLOT_NEED) or link_slots = -1 */
 #define NWAYHIP_FLAG_LOOKBACK 16         /* the single-pass scan timed out: repeat with link_slots = -1 */
-#define NWAYHIP_FLAG_BARRIER 32          /* the sweep launch that also registers the primaries did not get the GPU to itself
-                                            (its workgroups wait for each other): repeat without NWAYHIP_ENABLE_FUSED_FRONT */
+/* (32: unused since round 4 -- it was the grid barrier of round 3's registration-inside-the-sweep variant) */
 #define NWAYHIP_FLAG_QUAD_DEEP 64        /* k = 3 tail with four lanes per primary (k_tail3q): a primary has three or more candidates in a
                                             catalogue: repeat with NWAYHIP_DISABLE_QUAD3 */
 
@@ -119,11 +119,7 @@ typedef struct nwayhip_match_params {
 #define NWAYHIP_DISABLE_FUSED_CORRECTION 4 /* NWAYHIP_CORRECTION_CLI: k_correct behind the general back end instead of the fused tails */
 #define NWAYHIP_DISABLE_ONE_SWEEP 8      /* sparse k >= 3: one sweep launch per secondary catalogue instead of one for all */
 #define NWAYHIP_DISABLE_QUAD3 16         /* sparse k = 3: k_tailk<3> (one lane per primary) instead of k_tail3q (four) */
-#define NWAYHIP_ENABLE_FUSED_FRONT 1     /* the registration of the primaries INSIDE the sweep launch (front.inc: k_sweep<.., FUSED>;
-                                            sparse front with the bitmap in LDS): one launch and one kernel boundary fewer,
-                                            the first tiles hashed across a grid barrier.  Measured no faster than the two
-                                            launches and in need of the whole GPU (NWAYHIP_FLAG_BARRIER):
-                                            off unless asked for */
+/* (1: unused since round 4 -- round 3's registration inside the sweep launch, measured no faster and removed) */
 #define NWAYHIP_ENABLE_QUAD3 2           /* sparse k = 3: k_tail3q whatever the density of chance neighbours (default: below 0.02 per primary) */
 
 /* Output table, SoA, `capacity` rows allocated by the caller.  Columns follow
@@ -215,7 +211,7 @@ int32_t nwayhip_plan_path(const nwayhip_plan* plan);
 #define NWAYHIP_DESC_TAIL 4              /* NWAYHIP_TAIL_* */
 #define NWAYHIP_DESC_FOLD_LOG2 5         /* large-table sweep: bits of the folded bitmap, log2 (else 0) */
 #define NWAYHIP_DESC_ONE_SWEEP 6         /* 1: all secondary catalogues share one sweep launch */
-#define NWAYHIP_DESC_FUSED_FRONT 7       /* 1: that launch also registers the primaries */
+/* (word 7: always 0 since round 4) */
 #define NWAYHIP_SWEEP_GENERAL 0          /* survivors to regions, k_pairs + k_links behind it */
 #define NWAYHIP_SWEEP_LDS 1              /* sparse front, occupancy bitmap in LDS (tables up to 2^20 positions) */
 #define NWAYHIP_SWEEP_BIG 2              /* sparse front, bitmap in L2, folded copy in LDS */

@@ -21,16 +21,17 @@ ST_ROWS, ST_FLAGS, ST_REGISTRATIONS, ST_TESTS, ST_REGION_NEED, ST_SLOT_NEED = 0,
 LINK_SLOTS_CAP = 128
 LINK_SLOTS_MAX_FUSED = 8  # most slots of the one-launch fused tails (sparse.inc: LINK_SLOTS_MAX)
 ST_SURVIVORS, ST_PAIRS, ST_NOTFLAT = 8, 16, 24
-FLAG_PAIR_OVERFLOW, FLAG_ROW_OVERFLOW, FLAG_REG_OVERFLOW, FLAG_SLOT_OVERFLOW, FLAG_LOOKBACK, FLAG_BARRIER, FLAG_QUAD_DEEP = 1, 2, 4, 8, 16, 32, 64
+FLAG_PAIR_OVERFLOW, FLAG_ROW_OVERFLOW, FLAG_REG_OVERFLOW, FLAG_SLOT_OVERFLOW, FLAG_LOOKBACK, FLAG_QUAD_DEEP = 1, 2, 4, 8, 16, 64
 PATH_GENERAL, PATH_SPARSE, PATH_HYBRID = 0, 1, 2
 SCHEME_FLAT, SCHEME_SPHERE = 0, 1
 STAGES = 8
 STAGE_NAMES = ['register', 'sweep', 'pairs', 'lists', 'expand', 'rows', 'groups']
 CORRECTION_NONE, CORRECTION_CLI = 0, 1
 DISABLE_DENSE3, DISABLE_HYBRID, DISABLE_FUSED_CORRECTION, DISABLE_ONE_SWEEP, DISABLE_QUAD3 = 1, 2, 4, 8, 16
-ENABLE_FUSED_FRONT, ENABLE_QUAD3 = 1, 2
+ENABLE_QUAD3 = 2
+ABI_VERSION = 2  # include/nwayhip.h: NWAYHIP_ABI_VERSION
 DESC_WORDS = 8
-DESC_NAMES = ['path', 'link_slots', 'direct_log2', 'sweep', 'tail', 'fold_log2', 'one_sweep', 'fused_front']
+DESC_NAMES = ['path', 'link_slots', 'direct_log2', 'sweep', 'tail', 'fold_log2', 'one_sweep', 'reserved']
 SWEEP_GENERAL, SWEEP_LDS, SWEEP_BIG = 0, 1, 2
 SWEEP_NAMES = ['general', 'lds', 'big']
 TAIL_GENERAL, TAIL_SPARSE2, TAIL_DENSE2, TAIL_SPARSEK, TAIL_DENSE3, TAIL_HYBRID = 0, 1, 2, 3, 4, 5
@@ -139,8 +140,8 @@ def load():
 		fn = getattr(lib, name)
 		fn.restype = restype
 		fn.argtypes = argtypes
-	if lib.nwayhip_version() != 1:
-		raise NwayHipError('ABI version mismatch: library %d, binding 1' % lib.nwayhip_version())
+	if lib.nwayhip_version() != ABI_VERSION:
+		raise NwayHipError('ABI version mismatch: library %d, binding %d' % (lib.nwayhip_version(), ABI_VERSION))
 	_lib = lib
 	return lib
 
@@ -553,12 +554,6 @@ def run_plan(sizes, params, catalogues, cap_pairs, cap_rows, device, max_retries
 			tries[kind] += 1
 			if tries[kind] > max_retries:
 				raise NwayHipError('match table capacity could not be settled (%s, %d attempts; status flags %d)' % (kind, max_retries, flags))
-		if flags & FLAG_BARRIER:
-			# the fused front's workgroups wait for each other and did not get the GPU to themselves (another
-			# process' kernels on it): the registration as a launch of its own from now on
-			spend('path')
-			params.enable = int(params.enable) & ~ENABLE_FUSED_FRONT
-			continue
 		if flags & FLAG_QUAD_DEEP:
 			# a primary with three or more candidates in one catalogue: the 3-way tail with four lanes per primary
 			# leaves those to the one that walks them (csrc/tail3q.inc)

@@ -35,7 +35,7 @@ def test_library_exports_every_declared_symbol(built):
 		assert hasattr(lib, name), 'libnwayhip.so does not export %s' % name
 	assert sorted(_hip.SYMBOLS) == declared, 'ctypes binding and header disagree'
 	bound = _hip.load()
-	assert bound.nwayhip_version() == 1
+	assert bound.nwayhip_version() == _hip.ABI_VERSION == 2
 	assert isinstance(bound.nwayhip_last_error(), bytes)
 
 

@@ -237,36 +237,6 @@ def test_a_cluster_with_more_candidates_than_slots_keeps_the_sparse_front(k):
 	both_paths(nw, tabs, 8.0)
 
 
-@pytest.mark.parametrize('k,flat', [(2, False), (2, True), (3, False), (3, True)])
-def test_fused_front_equals_separate_registration(k, flat):
-	"""the registration inside the sweep launch (front.inc: k_sweep<.., FUSED>, NWAYHIP_ENABLE_FUSED_FRONT: off by default,
-	kept as a measured variant; workgroups register their share, park the hashes of their first tiles, meet at the
-	barrier) against the registration as a launch of its own: the same
-	table bit for bit, also where a workgroup's slice has fewer tiles than it parks and where it has none"""
-	import bench
-	import nway_amd as nw
-	from nway_amd import _hip
-	rng = np.random.default_rng(31 + k)
-	for n0, n1 in ((20000, 3000001), (700, 90001), (300, 1500), (1000, 3)):
-		if flat:
-			tabs = patch_tables(rng, [n0] + [n1] * (k - 1), 3.0, [rng.uniform(0.3, 1.5, size=n0)] + [0.2] * (k - 1))
-		else:
-			prim, sec = bench.make_workload(n0, n1, int(rng.integers(1, 1000)))
-			tabs = [prim] + [dict(bench.make_workload(n0, n1, int(rng.integers(1, 1000)))[1], name='S%d' % c, error=0.2 * np.ones(n1)) for c in range(1, k)]
-			for c in range(1, k):  # counterparts of the same primaries in every catalogue
-				m = min(int(0.7 * n0), n1)
-				tabs[c]['ra'][:m] = prim['ra'][:m]
-				tabs[c]['dec'][:m] = np.clip(prim['dec'][:m] + rng.normal(0, 0.5, size=m) / 3600., -90, 90)
-		fused, st = hip_table(nw, tabs, 5.0, 0.9, tuning=dict(enable=_hip.ENABLE_FUSED_FRONT))
-		assert int(st[1]) == 0 and fused['_desc']['fused_front'] == 1 and fused['_desc']['sweep'] == 'lds'
-		plain, st = hip_table(nw, tabs, 5.0, 0.9)
-		assert int(st[1]) == 0 and plain['_desc']['fused_front'] == 0
-		for key in fused:
-			if not key.startswith('_'):
-				np.testing.assert_array_equal(fused[key], plain[key], err_msg='%s (n0 = %d, n1 = %d)' % (key, n0, n1))
-		assert len(fused['ncat']) >= n0
-
-
 @pytest.mark.parametrize('k', [2, 3])
 def test_fields_with_more_than_64_links_per_primary(k):
 	"""~40 chance neighbours per primary: up to 128 slots the sparse front keeps such a field (dense 2-way tail;

@@ -145,16 +145,29 @@ def test_environment_is_ignored_without_the_development_guard(monkeypatch):
 	assert (d['link_slots'], d['direct_log2'], d['sweep']) == (8, 20, 'lds')
 
 
+def quad3_deep(n0, lams):
+	"""plan.inc: expected primaries of a run with a counterpart and two or more chance candidates in a catalogue"""
+	return sum(n0 * (1 - math.exp(-1.25 * lam) * (1 + 1.25 * lam)) for lam in lams)
+
+
 def test_four_lanes_per_primary_of_a_sparse_three_way_field():
-	"""k = 3, fewer than 0.02 chance neighbours per primary: k_tail3q (a primary with three candidates in a catalogue
-	sends the run back to k_tailk, which must stay rare); the caller's switches either way; never for other k"""
+	"""k = 3: k_tail3q where a RUN is unlikely to meet a primary with three candidates in a catalogue (such a primary sends
+	the whole run back to k_tailk): expected number of them below 0.1 -- a bound on chance neighbours per primary that
+	tightens with the number of primaries; the caller's switches either way; never for other k"""
 	from nway_amd import _hip
 	n = [100000, 1000000, 1000000]
-	below, above = describe(n, 0.019), describe(n, 0.021)
+	lam_edge = math.sqrt(0.1 / (2 * 100000 * 1.25**2 / 2))   # n0 * 2 catalogues * mu^2 / 2 = 0.1
+	assert quad3_deep(100000, [lam_edge * 0.98] * 2) < 0.1 < quad3_deep(100000, [lam_edge * 1.02] * 2)
+	below, above = describe(n, lam_edge * 0.98), describe(n, lam_edge * 1.02)
 	assert (below['tail'], below['link_slots'], below['split_capable']) == ('quad3', 8, 1)
 	assert (above['tail'], above['link_slots'], above['split_capable']) == ('sparsek', 8, 1)
+	# BASELINE configs[3] (1e5 x 1e6 x 1e6 on the whole sky, 10 arcsec: lambda = 5.9e-4) takes it; ten times the primaries do not
+	lam_c4s = 1e6 / SKY * math.pi * (10 / 3600.)**2
+	assert describe(n, lam_c4s)['tail'] == 'quad3' and quad3_deep(100000, [lam_c4s] * 2) < 0.06
+	assert describe([1000000, 1000000, 1000000], lam_c4s)['tail'] == 'sparsek'
+	assert describe([1000, 100000, 100000], 0.005)['tail'] == 'quad3' and describe(n, 0.005)['tail'] == 'sparsek'
 	assert describe(n, 0.3, tuning=dict(enable=_hip.ENABLE_QUAD3))['tail'] == 'quad3'
-	assert describe(n, 0.001, tuning=dict(disable=_hip.DISABLE_QUAD3))['tail'] == 'sparsek'
-	assert describe(n, 0.001, link_slots=1)['tail'] == 'sparsek'   # (its lanes read two slots of every primary)
-	assert describe(n, 0.001, correction=_hip.CORRECTION_CLI)['tail'] == 'quad3'
-	assert describe(n[:2], 0.001)['tail'] == 'sparse2' and describe(n + [1000000], 0.001)['tail'] == 'sparsek'
+	assert describe(n, 0.0005, tuning=dict(disable=_hip.DISABLE_QUAD3))['tail'] == 'sparsek'
+	assert describe(n, 0.0005, link_slots=1)['tail'] == 'sparsek'   # (its lanes read two slots of every primary)
+	assert describe(n, 0.0005, correction=_hip.CORRECTION_CLI)['tail'] == 'quad3'
+	assert describe(n[:2], 0.0005)['tail'] == 'sparse2' and describe(n + [1000000], 0.0005)['tail'] == 'sparsek'

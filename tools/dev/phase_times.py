@@ -38,7 +38,7 @@ plan, st = _hip.run_plan(sizes, params, cats, cap_pairs, cap_rows, dev, lean=Tru
 for _ in range(5):
 	plan.enqueue(cats)
 torch.cuda.synchronize()
-fused = plan.description['fused_front'] == 1
+fused = False
 names = {0: ('k_register_x', ['start', None, 'claims + stores landed', 'end']),
 	1: ('k_sweep', ['start', 'bitmap in LDS', 'wave 0 done streaming', 'all waves done', 'probes landed', 'end', 'barrier passed']),
 	2: ('k_tail2', ['start', 'cnt/slot/sigma landed', 'block scan', 'lookback', 'rows landed', 'group stats landed'])}
