@@ -81,6 +81,19 @@ def make_workload(n_primary, n_secondary, seed, true_fraction=0.8, sigma_seconda
 	return primary, secondary
 
 
+def kernel_source_hash():
+	"""sha256 over the kernel sources, as tools/summarize_profile.py stamps it into profiles/sweep_traffic.json"""
+	import glob
+	import hashlib
+	h = hashlib.sha256()
+	files = sorted(glob.glob(os.path.join(ROOT, 'nway_amd', 'csrc', '*.inc')) + glob.glob(os.path.join(ROOT, 'nway_amd', 'csrc', '*.hip'))) + [
+		os.path.join(ROOT, 'include', 'nwayhip.h')]
+	for f in files:
+		h.update(os.path.basename(f).encode())
+		h.update(open(f, 'rb').read())
+	return h.hexdigest()[:16]
+
+
 def pass_bytes(tables, rows):
 	"""algorithmic bytes of one pass, SURVEY.md 8(d): every input column read once (ra, dec, and the
 	positional error where it is a column) + every output column written once (k = 2: 66 B per row,
@@ -121,7 +134,9 @@ def cpu_baseline(primary, secondary, radius, completeness, numpy_sample):
 	best = legs.get('all_cores', legs['one_core'])
 	out = dict(value=best['value'], unit='candidate evaluations/s', cores=best['cores'], kind='port',
 		sample='oracle/nway_oracle.c built with -fopenmp, %d threads (os.sched_getaffinity): the whole workload, %d primaries x %d secondaries, '
-			'%d rows in %.2f s' % (best['cores'], len(primary['ra']), n, best['rows'], best['seconds']),
+			'%d rows in %.2f s -- NOT a tuned CPU code: the declination sort of the secondaries is per-thread chunk sorts + a pairwise merge tree whose last '
+			'levels run on few threads, the key fill and the final concatenation are serial; the one-core leg beside it is the like-for-like figure' % (
+			best['cores'], len(primary['ra']), n, best['rows'], best['seconds']),
 		one_core=legs['one_core'], numpy_one_thread=legs['numpy_one_thread'],
 		reference_note='the reference itself (pure Python, one thread; it cannot travel to the GPU box) measured in the build container '
 			'on its own fixtures: 8.4e4 rows/s (tests/elltest 2-way, 37 706 rows in 0.45 s), 5.3e4 rows/s (3-way, 450 435 rows in 8.5 s)')
@@ -216,6 +231,119 @@ def table_check(plan, names, cpu_table):
 	return out
 
 
+def make_workload3(n0, n1, n2, seed):
+	"""C4-S of SURVEY.md 8d (BASELINE configs[3]): uniform-sky 3-way; 80 % of the primaries have a counterpart in the first
+	secondary catalogue (sigma 0.1), 60 % in the second (0.5); the primaries' error is 1 arcsec"""
+	rng = np.random.default_rng(seed)
+	pra, pdec = uniform_sphere(rng, n0)
+	psig = np.ones(n0)
+	out = [dict(name='PRIM', ra=pra, dec=pdec, error=psig, area=SKY_AREA, mags=[], maghists=[], magnames=[])]
+	for name, n, sigma, frac in (('A', n1, 0.1, 0.8), ('B', n2, 0.5, 0.6)):
+		ra, dec = uniform_sphere(rng, n)
+		m = min(int(frac * n0), n)
+		slots = rng.choice(n, size=m, replace=False)
+		dec[slots] = np.clip(pdec[:m] + rng.normal(0, 1, size=m) * psig[:m] / 3600., -90, 90)
+		ra[slots] = (pra[:m] + rng.normal(0, 1, size=m) * psig[:m] / 3600. / np.maximum(np.cos(np.radians(pdec[:m])), 1e-6)) % 360
+		out.append(dict(name=name, ra=ra, dec=dec, error=sigma, area=SKY_AREA, mags=[], maghists=[], magnames=[]))
+	return out
+
+
+def job_bytes(sizes, error_columns, rows):
+	"""algorithmic bytes of a whole JOB: every input column once, every output column once"""
+	k = len(sizes)
+	b = sum(n * (16.0 + (8.0 if col else 0.0)) for n, col in zip(sizes, error_columns))
+	return b + (4 * k + 8 * (k * (k - 1) // 2) + 8 + 1 + 8 * 5 + 1) * rows
+
+
+def extra_configs(args, world, rank, device, dist, backend):
+	"""The jobs BASELINE names for several GPUs, measured in the SAME launch as the headline (whose default, weak scaling of
+	C3-S, is N x by construction): every job is FIXED in size and divided over the ranks, so value(N) / value(1) is its
+	strong-scaling curve.  One record per job, mode and carrier of the exchanges:
+	  c3s_split      C3-S as ONE job (1e5 x 1e7, 5"), secondary stream split (SecondarySplitMatch)
+	  c4s_rows       BASELINE configs[3]: 3-way 1e5 x 1e6 x 1e6, 10", primary rows sharded (ShardedMatch)
+	  c5_rows        BASELINE configs[4]: 5e5 x 1e8, 5", primary rows sharded
+	  c5_split       the same job, secondary stream split
+	Each rank generates ITS shard of the primaries and ITS slices of the secondaries (the counterparts of its primaries lie
+	in its own slices), so no rank ever holds a whole 1e8-row catalogue on the host.  NWAY_BENCH_EXTRA_SCALE (tests) scales
+	every catalogue size."""
+	import torch
+	from nway_amd import distributed, _hip
+	scale = float(os.environ.get('NWAY_BENCH_EXTRA_SCALE', '1'))
+	sz = lambda n: max(int(n * scale), 8 * world)
+	jobs = [('c3s_split', 'split', [sz(1e5), sz(1e7)], 5.0), ('c4s_rows', 'rows', [sz(1e5), sz(1e6), sz(1e6)], 10.0),
+		('c5_rows', 'rows', [sz(5e5), sz(1e8)], 5.0), ('c5_split', 'split', [sz(5e5), sz(1e8)], 5.0)]
+	only = os.environ.get('NWAY_BENCH_EXTRA_ONLY')
+	comms = ['torch'] + (['rccl'] if backend == 'nccl' else [])
+	steps, warm = min(args.steps, 20), min(max(args.warmup, 2), 5)
+	records = []
+	for name, mode, sizes, radius in jobs:
+		if only and name not in only.split(','):
+			continue
+		local = [distributed.shard_bounds(n, world) for n in sizes]
+		mine = [int(b[rank + 1] - b[rank]) for b in local]
+		if len(sizes) == 2:
+			tabs = list(make_workload(mine[0], mine[1], args.seed + 77 + 1000 * rank))
+		else:
+			tabs = make_workload3(mine[0], mine[1], mine[2], args.seed + 77 + 1000 * rank)
+		for t, n in zip(tabs, sizes):
+			t['area'] = SKY_AREA  # (of the whole catalogue: the engines take the densities from the global sizes)
+		for comm in comms:
+			rec = dict(job=name, mode=('secondary-stream slices + candidate routing' if mode == 'split' else 'primary-row shards'),
+				sizes=sizes, radius_arcsec=radius, exchanges=('nwayhip_comm_* (RCCL behind the C ABI)' if comm == 'rccl' else 'torch.distributed (%s)' % backend),
+				scaling='strong', n_gpus=world)
+			engine = None
+			try:
+				torch.cuda.synchronize(device)
+				t0 = time.perf_counter()
+				cls = distributed.SecondarySplitMatch if mode == 'split' else distributed.ShardedMatch
+				engine = cls(tabs[0], tabs[1:], radius, args.completeness, device, comm=('rccl' if comm == 'rccl' else None))
+				torch.cuda.synchronize(device)
+				rec['setup_s'] = time.perf_counter() - t0
+				for _ in range(warm):
+					engine.step()
+				torch.cuda.synchronize(device)
+				dist.barrier()
+				torch.cuda.synchronize(device)
+				t0 = time.perf_counter()
+				for _ in range(steps):
+					engine.step()
+				torch.cuda.synchronize(device)
+				el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
+				dist.barrier()
+				dist.all_reduce(el, op=dist.ReduceOp.MAX)
+				st = engine.read_status()
+				flags = torch.tensor([int(st[_hip.ST_FLAGS])], dtype=torch.int64, device=device)
+				dist.all_reduce(flags, op=dist.ReduceOp.MAX)
+				seen = torch.ones(1, dtype=torch.int64, device=device)
+				dist.all_reduce(seen)
+				rows = engine.total_rows()
+				ms = float(el.item()) * 1e3 / steps
+				jb = job_bytes(sizes, [True] + [False] * (len(sizes) - 1), rows)
+				rec.update(ms_per_step=ms, steps=steps, rows=rows, value=rows / (ms * 1e-3), ranks_seen=int(seen.item()), flags=int(flags.item()),
+					job_bytes=jb, pass_frac=jb / (ms * 1e-3) / 1e9 / (HBM_PEAK_GBS * world),
+					pass_frac_note='algorithmic bytes of the WHOLE job (SURVEY 8d) / step time / (N x 8 TB/s)',
+					rank0_rows=engine.local_rows(), rank0_pass_frac=engine.pass_bytes(engine.local_rows()) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+					path=(engine.plan.description if engine.plan is not None else None))
+				if mode == 'split':
+					rec['exchange_block_records'] = engine.capacity
+					rec['exchange_block_records_used'] = engine.block_records_used
+					rec['exchange_bytes_per_peer_per_step'] = 32 * (engine.capacity + 1) * (len(sizes) - 1)
+				else:
+					rec['setup_exchange_bytes'] = engine.gathered_bytes
+			except Exception as e:  # (a job that does not fit a mode is a record, not the end of the run; every rank raises alike)
+				rec['error'] = '%s: %s' % (type(e).__name__, e)
+			finally:
+				if engine is not None:
+					if getattr(engine, 'plan', None) is not None:
+						engine.plan.close()
+					if getattr(engine, 'comm', None) is not None:
+						engine.comm.close()
+				del engine
+				torch.cuda.empty_cache()
+			records.append(rec)
+	return records
+
+
 def main():
 	ap = argparse.ArgumentParser()
 	ap.add_argument('--gpus', type=int, default=1)
@@ -235,6 +363,8 @@ def main():
 	ap.add_argument('--two-pipelines', type=int, default=1, help='also time the steps alternating over two (or this many, if > 2) independent pipelines (reported beside, never as, `value`); 0 = skip')
 	ap.add_argument('--comm', choices=['torch', 'rccl'], default=os.environ.get('NWAY_BENCH_COMM', 'torch'),
 		help='who carries the exchanges of the multi-GPU modes: torch.distributed (default) or the library\'s own RCCL calls behind the C ABI (nwayhip_comm_*)')
+	ap.add_argument('--extras', type=int, default=int(os.environ.get('NWAY_BENCH_EXTRAS', '1')),
+		help='N > 1: also measure, in the same launch, the fixed-size jobs BASELINE names for several GPUs (extra_configs: C3-S as one job, configs[3], configs[4]; both sharding modes, both carriers of the exchanges); 0 = skip')
 	ap.add_argument('--streams', type=int, default=int(os.environ.get('NWAY_BENCH_STREAMS', '1')),
 		help='independent pipelines (own workspace, own output table, own HIP stream) the steps alternate over')
 	args = ap.parse_args()
@@ -433,8 +563,12 @@ def main():
 				rec = json.load(open(tf))
 				if rec.get('n_secondary') == n_sec_swept:
 					traffic = rec.get('hbm_bytes_per_launch')
+					same = rec.get('kernel_source_sha16') == kernel_source_hash()
 					traffic_source = ('NOT measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same command, '
-						'recorded in profiles/sweep_traffic.json (%s)' % rec.get('round', 'earlier round'))
+						'recorded in profiles/sweep_traffic.json (%s, git %s%s, kernel sources %s): %s' % (rec.get('round', 'earlier round'),
+						rec.get('git_head'), ' + uncommitted changes' if rec.get('git_dirty') else '', rec.get('kernel_source_sha16'),
+						'the kernel sources of this tree are the ones that were measured' if same else
+						'STALE -- the kernel sources of this tree differ from the measured build (rerun tools/profile_round.sh)'))
 			except Exception:
 				traffic = None
 		# the whole pass, SURVEY 8(d): rank 0's pass (its primaries, the secondaries it streams, its rows)
@@ -514,6 +648,20 @@ def main():
 			assert out['check']['ok'], 'the timed table differs from the CPU table: %r' % (out['check'],)
 		else:
 			out['cpu_baseline'] = None
+	extras = None
+	if (world > 1 or force_dist) and args.extras:
+		# (every rank takes part; the headline's engine has been measured and is released first)
+		if engine is not None:
+			if getattr(engine, 'plan', None) is not None:
+				engine.plan.close()
+			engine = None
+			plan = None
+			plans = []
+			torch.cuda.empty_cache()
+		extras = extra_configs(args, world, rank, device, dist, backend)
+	if rank == 0:
+		if extras is not None:
+			out['extra_configs'] = extras
 		print(json.dumps(out))
 	if world > 1 or force_dist:
 		dist.destroy_process_group()

@@ -144,10 +144,12 @@ def run_match(match_tables, match_radius, prior_completeness=1.0, prob_ratio_sec
 	ncats = len(match_tables)
 	if ncats < 2 or ncats > _hip.MAXCAT:
 		raise ValueError('between 2 and %d catalogues can be matched, got %d' % (_hip.MAXCAT, ncats))
-	ratables = [(numpy.asarray(t['ra'], dtype=float), numpy.asarray(t['dec'], dtype=float)) for t in match_tables]
 	err = match_radius / 60. / 60 if err_deg is None else err_deg  # __init__.py:128
+	# all columns go up behind one synchronisation; the flat-cell condition (fastskymatch.py:94-98) is then read off the
+	# device columns (one small kernel per catalogue, one read-back) instead of four passes over every host column
+	cats = _hip.DeviceCatalogue.from_columns([(t['ra'], t['dec'], numpy.asarray(t['error'], dtype=float)) for t in match_tables], device)
 	if scheme is None:
-		scheme = choose_scheme(ratables, err)
+		scheme = _hip.scheme_from_extents(_hip.catalogue_extents(cats), err)
 	if scheme == _hip.SCHEME_FLAT:
 		logger.log('matching: using fast flat-sky approximation for this match')
 	else:
@@ -159,7 +161,6 @@ def run_match(match_tables, match_radius, prior_completeness=1.0, prob_ratio_sec
 		radius_filter=radius_filter, correction=correction, finalize=finalize,
 		sphere_cell_factor=sphere_cell_factor, bitmap_bits=bitmap_bits, link_slots=link_slots, table_slots=table_slots, f32_roundtrip=f32_roundtrip,
 		tuning=tuning)
-	cats = [_hip.DeviceCatalogue(ra, dec, numpy.asarray(t['error'], dtype=float), device) for (ra, dec), t in zip(ratables, match_tables)]
 	sizes = [c.n for c in cats]
 	cap_pairs, cap_rows = _estimate_capacities(sizes, [t['area'] * 1.0 for t in match_tables], match_radius, scheme, radius_filter)
 	plan, status = _hip.run_plan(sizes, params, cats, cap_pairs, cap_rows, device, lean=lean)
@@ -235,6 +236,32 @@ def nway_match(match_tables, match_radius, prior_completeness,
 		raise EmptyResultException('No matches.')
 	logger.log('matching: %6d matches after filtering by search radius' % res.nrows)
 
+	if not has_mags:
+		# the whole table with one transfer, the DataFrame over views of the page-locked buffer it arrived in (no copy on the host)
+		logger.log('')
+		logger.log('Computing final probabilities ...')
+		pairs = _hip.pair_columns(k)
+		f64 = ['sep%d' % i for i in range(len(pairs))] + ['sep_max', 'log_bf', 'log_bf_corrected', 'dist_post', 'p_single', 'p_any', 'p_i']
+		idx, (ncat, flag), fc = res.plan.download_table(res.nrows, f64)
+		cols = OrderedDict()
+		for c in range(k):
+			cols[names[c]] = idx[c]
+		for i, (a, b) in enumerate(pairs):
+			cols['Separation_%s_%s' % (names[a], names[b])] = fc[i]
+		np_ = len(pairs)
+		cols['Separation_max'] = fc[np_]
+		cols['ncat'] = ncat
+		cols['dist_bayesfactor_uncorrected'] = fc[np_ + 1]
+		cols['dist_bayesfactor'] = fc[np_ + 2]
+		cols['dist_post'] = fc[np_ + 3]
+		cols['p_single'] = fc[np_ + 4]
+		cols['match_flag'] = flag
+		cols['prob_has_match'] = fc[np_ + 5]
+		cols['prob_this_match'] = fc[np_ + 6]
+		table = pandas.DataFrame(cols, copy=False)
+		res.plan.release()
+		return _truncate_table(table, min_prob, logger=logger)
+
 	cols = OrderedDict()
 	for c in range(k):
 		cols[names[c]] = res.to_host('idx', c).astype(numpy.int64)
@@ -247,22 +274,15 @@ def nway_match(match_tables, match_radius, prior_completeness,
 	cols['dist_post'] = res.to_host('dist_post')
 	table = pandas.DataFrame(cols)
 
-	if has_mags:
-		from . import magpriors
-		table, total = magpriors.apply_magnitude_biasing(match_tables, table, res, mag_include_radius, mag_exclude_radius,
-			magauto_post_single_minvalue, store_mag_hists, logger=logger)
-		logger.log('')
-		logger.log('Computing final probabilities ...')
-		stats = magpriors.final_probabilities_device(res, total, prob_ratio_secondary)
-		table = table.assign(p_single=stats['p_single'], match_flag=stats['match_flag'].astype(numpy.int64),
-			prob_has_match=stats['p_any'], prob_this_match=stats['p_i'])
-	else:
-		logger.log('')
-		logger.log('Computing final probabilities ...')
-		table = table.assign(p_single=res.to_host('p_single'),
-			match_flag=res.to_host('match_flag').astype(numpy.int64),
-			prob_has_match=res.to_host('p_any'), prob_this_match=res.to_host('p_i'))
-	res.plan.close()
+	from . import magpriors
+	table, total = magpriors.apply_magnitude_biasing(match_tables, table, res, mag_include_radius, mag_exclude_radius,
+		magauto_post_single_minvalue, store_mag_hists, logger=logger)
+	logger.log('')
+	logger.log('Computing final probabilities ...')
+	stats = magpriors.final_probabilities_device(res, total, prob_ratio_secondary)
+	table = table.assign(p_single=stats['p_single'], match_flag=stats['match_flag'].astype(numpy.int64),
+		prob_has_match=stats['p_any'], prob_this_match=stats['p_i'])
+	res.plan.release()
 	return _truncate_table(table, min_prob, logger=logger)
 
 

@@ -7,6 +7,7 @@ fallback: if the HIP library or a GPU is missing, every compute entry point rais
 from __future__ import annotations
 
 import ctypes
+import threading
 import os
 import sys
 
@@ -262,6 +263,46 @@ def to_device(array, device, dtype=None):
 	return t.from_numpy(a).to(device)
 
 
+def upload_columns(arrays, device):
+	"""several host columns -> float64 device tensors with ONE synchronisation: the large ones are page-locked in place, all
+	copies are issued, the stream is waited for once, the arrays are released (``_upload_large`` does this per column: nine
+	round trips for a 3-way match).  Tensors already on a device pass through ``to_device``."""
+	t = torch()
+	dev = t.device(device)
+	rt = t.cuda.cudart()
+	outs, registered = [], []
+	try:
+		for array in arrays:
+			if isinstance(array, t.Tensor) or dev.type != 'cuda':
+				outs.append(to_device(array, device))
+				continue
+			a = numpy.ascontiguousarray(numpy.asarray(array), dtype=numpy.float64)
+			if a.nbytes < UPLOAD_PIN_BYTES or os.environ.get('NWAY_UPLOAD', '') == 'staged':
+				outs.append(to_device(a, device))
+				continue
+			if not a.flags.writeable:
+				a = a.copy()
+			ok = False
+			try:
+				ok = int(rt.cudaHostRegister(a.ctypes.data, a.nbytes, 0)) == 0
+			except Exception:
+				ok = False
+			if not ok:
+				outs.append(to_device(a, device))
+				continue
+			registered.append(a)
+			out = t.empty(a.shape, dtype=t.float64, device=dev)
+			out.copy_(t.from_numpy(a), non_blocking=True)
+			outs.append(out)
+		if registered:
+			t.cuda.current_stream(dev).synchronize()
+			upload_mode['last'] = 'registered'
+	finally:
+		for a in registered:
+			rt.cudaHostUnregister(a.ctypes.data)
+	return outs
+
+
 def current_stream_ptr(device):
 	return ctypes.c_void_p(torch().cuda.current_stream(device).cuda_stream)
 
@@ -283,10 +324,22 @@ def catalogue_extent(ra, dec):
 	return float(lo), float(hi), float(absdec), int(nnan)
 
 
+def catalogue_extents(catalogues):
+	"""``catalogue_extent`` of several device catalogues with one synchronisation"""
+	t = torch()
+	if not catalogues:
+		return []
+	dev = catalogues[0].ra.device
+	out = t.empty((len(catalogues), 4), dtype=t.float64, device=dev)
+	for i, c in enumerate(catalogues):
+		check(load().nwayhip_catalogue_extent(ptr(c.ra), ptr(c.dec), int(c.n), ptr(out[i]), current_stream_ptr(dev)))
+	return [(float(lo), float(hi), float(absdec), int(nnan)) for lo, hi, absdec, nnan in out.cpu().numpy()]
+
+
 def scheme_from_extents(extents, err):
 	"""flat-cell condition of fastskymatch.py:94-98 evaluated on per-catalogue extents"""
 	for lo, hi, absdec, nnan in extents:
-		if not (err < 1 and lo > 10 * err and hi < 360 - 10 * err and absdec < 45):
+		if not (err < 1 and nnan == 0 and lo > 10 * err and hi < 360 - 10 * err and absdec < 45):  # (a NaN coordinate fails the host test too)
 			return SCHEME_SPHERE
 	return SCHEME_FLAT
 
@@ -363,6 +416,31 @@ class DeviceCatalogue(object):
 	def struct(self):
 		return Catalogue(ptr(self.ra), ptr(self.dec), ptr(self.sigma), self.sigma_const, self.n)
 
+	@classmethod
+	def from_columns(cls, columns, device):
+		"""[(ra, dec, error), ...] -> catalogues, all columns uploaded behind one synchronisation (upload_columns)"""
+		flat, scalar = [], []
+		for ra, dec, error in columns:
+			is_scalar = numpy.ndim(error) == 0 and not isinstance(error, torch().Tensor)
+			scalar.append(is_scalar)
+			flat += [ra, dec] + ([] if is_scalar else [error])
+		dev = upload_columns(flat, device)
+		out, at = [], 0
+		for (ra, dec, error), is_scalar in zip(columns, scalar):
+			c = cls.__new__(cls)
+			c.ra, c.dec = dev[at], dev[at + 1]
+			at += 2
+			if is_scalar:
+				c.sigma, c.sigma_const = None, float(error)
+			else:
+				c.sigma, c.sigma_const = dev[at], 0.0
+				at += 1
+			c.n = int(c.ra.shape[0])
+			if c.dec.shape[0] != c.n or (c.sigma is not None and c.sigma.shape[0] != c.n):
+				raise ValueError('catalogue columns differ in length')
+			out.append(c)
+		return out
+
 
 class MatchPlan(object):
 	"""Parameters + capacities + device buffers for repeated runs of the match pipeline."""
@@ -409,15 +487,25 @@ class MatchPlan(object):
 			self.workspace = t.empty(self.workspace_bytes + 256, dtype=t.uint8, device=self.device)
 			self.status = t.zeros(STATUS_WORDS, dtype=t.int64, device=self.device)
 			cap = self.cap_rows
-			f64 = lambda: t.empty(cap, dtype=t.float64, device=self.device)
+			# the columns of one type are the rows of ONE tensor (stride: the capacity rounded up to 64 rows, every column
+			# 256-byte aligned): what a caller downloads is then three strided copies and one transfer (download_table)
+			stride = (cap + 63) // 64 * 64
+			f64_names = ['sep%d' % i for i in range(len(pair_columns(self.ncat)))] + [n for n in
+				('sep_max', 'log_bf', 'log_bf_corrected', 'prior', 'dist_post', 'p_single', 'p_any', 'p_i') if n not in skip]
+			self.block_f64 = t.empty((len(f64_names), stride), dtype=t.float64, device=self.device)
+			self.block_i32 = t.empty((self.ncat, stride), dtype=t.int32, device=self.device)
+			self.block_i8 = t.empty((2, stride), dtype=t.int8, device=self.device)
+			self.f64_row = dict((n, i) for i, n in enumerate(f64_names))
 			self.cols = {}
-			self.cols['idx'] = [t.empty(cap, dtype=t.int32, device=self.device) for _ in range(self.ncat)]
-			self.cols['sep'] = [f64() for _ in pair_columns(self.ncat)]
+			self.cols['idx'] = [self.block_i32[c, :cap] for c in range(self.ncat)]
+			self.cols['sep'] = [self.block_f64[self.f64_row['sep%d' % i], :cap] for i in range(len(pair_columns(self.ncat)))]
 			for name in ('sep_max', 'log_bf', 'log_bf_corrected', 'prior', 'dist_post', 'p_single', 'p_any', 'p_i'):
-				self.cols[name] = None if name in skip else f64()
-			self.cols['ncat'] = t.empty(cap, dtype=t.int8, device=self.device)
-			self.cols['match_flag'] = t.empty(cap, dtype=t.int8, device=self.device)
+				self.cols[name] = None if name in skip else self.block_f64[self.f64_row[name], :cap]
+			self.cols['ncat'] = self.block_i8[0, :cap]
+			self.cols['match_flag'] = self.block_i8[1, :cap]
 			self.cols['group_start'] = t.empty(self.sizes[0] + 1, dtype=t.int64, device=self.device)
+			self.device_bytes = (self.workspace.numel() + self.block_f64.numel() * 8 + self.block_i32.numel() * 4 + self.block_i8.numel()
+				+ self.cols['group_start'].numel() * 8)
 		tab = Table()
 		tab.capacity = cap
 		for c in range(self.ncat):
@@ -428,6 +516,7 @@ class MatchPlan(object):
 			setattr(tab, name, self.cols[name].data_ptr() if self.cols[name] is not None else None)
 		if 'log_bf_corrected' in skip:
 			self.cols['log_bf_corrected'] = self.cols['log_bf']  # the same values: one tensor
+			self.f64_row['log_bf_corrected'] = self.f64_row['log_bf']
 		self.table_struct = tab
 		ws = self.workspace.data_ptr()
 		self.ws_ptr = (ws + 255) // 256 * 256
@@ -474,10 +563,50 @@ class MatchPlan(object):
 		"""synchronises; returns the status words as numpy int64"""
 		return self.status.cpu().numpy()
 
+	def download_table(self, nrows, f64_columns, with_idx=True, with_small=True):
+		"""The first ``nrows`` rows of the table on the host with ONE transfer and ONE synchronisation: the index columns
+		(as int64, what the reference's table holds), ncat and match_flag (int64) and the float columns named in
+		``f64_columns`` (cols keys; 'sep<i>' for the separation columns; a name may repeat: it then gets memory of its own)
+		are packed on the device -- one strided copy per type -- and come down into one page-locked buffer, of which the
+		returned arrays are views (no copy on the host; the buffer lives as long as one of them does and goes back to
+		torch's pinned-memory cache afterwards).  Returns (idx list, (ncat, match_flag) or None, list of float columns)."""
+		t = torch()
+		n = int(nrows)
+		ni = self.ncat if with_idx else 0
+		ns = 2 if with_small else 0
+		nf = len(f64_columns)
+		words = (ni + ns + nf) * n
+		if words == 0:
+			return [numpy.zeros(0, dtype=numpy.int64)] * ni, ((numpy.zeros(0, dtype=numpy.int64),) * 2 if ns else None), [numpy.zeros(0)] * nf
+		with t.cuda.device(self.device):
+			pack = t.empty(words, dtype=t.int64, device=self.device)
+			if ni:
+				pack[:ni * n].view(ni, n).copy_(self.block_i32[:, :n])   # (int32 -> int64 in the copy)
+			if ns:
+				pack[ni * n:(ni + ns) * n].view(ns, n).copy_(self.block_i8[:, :n])
+			if nf:
+				rows = t.tensor([self.f64_row[c] for c in f64_columns], dtype=t.int64, device=self.device)
+				t.index_select(self.block_f64[:, :n], 0, rows, out=pack[(ni + ns) * n:].view(t.float64).view(nf, n))
+			host = t.empty(words, dtype=t.int64, pin_memory=True)
+			host.copy_(pack, non_blocking=True)
+			t.cuda.current_stream(self.device).synchronize()
+		flat = host.numpy()
+		if os.environ.get('NWAY_DOWNLOAD', '') == 'copy':
+			flat = flat.copy()  # (pageable memory of the caller's own)
+		idx = [flat[c * n:(c + 1) * n] for c in range(ni)]
+		small = (flat[ni * n:(ni + 1) * n], flat[(ni + 1) * n:(ni + 2) * n]) if ns else None
+		f64 = [flat[(ni + ns + c) * n:(ni + ns + c + 1) * n].view(numpy.float64) for c in range(nf)]
+		return idx, small, f64
+
 	def close(self):
 		if getattr(self, 'handle', None):
 			self.lib.nwayhip_plan_destroy(self.handle)
 			self.handle = None
+
+	def release(self):
+		"""the caller is done with the table: the plan (workspace, table, staging) stays for the next match of the same shape
+		(plan cache below), or is closed"""
+		_plan_cache_put(self)
 
 	def __del__(self):
 		try:
@@ -524,6 +653,64 @@ def make_params(ncat, scheme, radius_arcsec, err_deg, dens, dens_plus, prior_tab
 CAPACITY_LIMIT = (1 << 31) - 4096  # row / link positions are int32 on the device
 
 
+# Plans of recent matches, kept for the next one of the same shape: nway_match on catalogues of a few hundred thousand rows
+# is host time (plan creation, 20-odd allocations, the capacity estimate and its repeats), not GPU time.  A released plan
+# waits here with its buffers; the key is everything it was created from.  `settled`: what a request ended up with after
+# its overflow repeats, so that the next identical request starts there.
+PLAN_CACHE_ENTRIES = 4
+PLAN_CACHE_BYTES = 1 << 30
+_plan_cache = []      # [(key, plan)], most recent last
+_plan_settled = {}    # request key -> (params bytes, cap_pairs, cap_rows)
+_plan_lock = threading.Lock()
+
+
+def _plan_key(sizes, params, cap_pairs, cap_rows, device, lean):
+	return (tuple(int(n) for n in sizes), bytes(params), int(cap_pairs), int(cap_rows), str(device), bool(lean))
+
+
+def _plan_cache_get(key):
+	with _plan_lock:
+		for i, (k, plan) in enumerate(_plan_cache):
+			if k == key:
+				del _plan_cache[i]
+				return plan
+	return None
+
+
+def _plan_cache_put(plan):
+	if getattr(plan, 'handle', None) is None:
+		return
+	key = getattr(plan, 'cache_key', None)
+	if key is None or plan.device_bytes > PLAN_CACHE_BYTES or os.environ.get('NWAY_PLAN_CACHE', '1') == '0':
+		plan.close()
+		return
+	evict = []
+	with _plan_lock:
+		_plan_cache.append((key, plan))
+		while len(_plan_cache) > PLAN_CACHE_ENTRIES or sum(p.device_bytes for _, p in _plan_cache) > PLAN_CACHE_BYTES:
+			evict.append(_plan_cache.pop(0)[1])
+	for p in evict:
+		p.close()
+
+
+def plan_cache_clear():
+	with _plan_lock:
+		old = [p for _, p in _plan_cache]
+		del _plan_cache[:]
+		_plan_settled.clear()
+	for p in old:
+		p.close()
+
+
+def _new_plan(sizes, params, cap_pairs, cap_rows, device, lean):
+	key = _plan_key(sizes, params, cap_pairs, cap_rows, device, lean)
+	plan = _plan_cache_get(key)
+	if plan is None:
+		plan = MatchPlan(sizes, params, cap_pairs, cap_rows, device, lean=lean)
+		plan.cache_key = key
+	return plan
+
+
 def run_plan(sizes, params, catalogues, cap_pairs, cap_rows, device, max_retries=6, lean=False):
 	"""enqueue, synchronise, grow the capacities on overflow; returns (plan, status).
 
@@ -533,8 +720,13 @@ def run_plan(sizes, params, catalogues, cap_pairs, cap_rows, device, max_retries
 	bound otherwise (an expansion level that overflowed ends the run: rows grow fourfold then)."""
 	tries = dict(table=0, path=0, pairs=0, rows=0, slots=0)
 	attempts = 0
+	request = _plan_key(sizes, params, cap_pairs, cap_rows, device, lean)
+	known = _plan_settled.get(request)
+	if known is not None:  # what this very request ended up with the last time
+		ctypes.memmove(ctypes.addressof(params), known[0], ctypes.sizeof(params))
+		cap_pairs, cap_rows = known[1], known[2]
 	while True:
-		plan = MatchPlan(sizes, params, cap_pairs, cap_rows, device, lean=lean)
+		plan = _new_plan(sizes, params, cap_pairs, cap_rows, device, lean)
 		plan.enqueue(catalogues)
 		attempts += 1
 		plan.attempts = attempts  # enqueues it took to settle the capacities (1 = the first guess held)
@@ -543,6 +735,8 @@ def run_plan(sizes, params, catalogues, cap_pairs, cap_rows, device, max_retries
 		if os.environ.get('NWAYHIP_TRACE'):
 			sys.stderr.write('run_plan: link_slots %d flags %d rows %d cap_pairs %d cap_rows %d\n' % (plan.link_slots, flags, int(st[ST_ROWS]), cap_pairs, cap_rows))
 		if flags == 0:
+			if attempts > 1 and len(_plan_settled) < 64:
+				_plan_settled[request] = (bytes(params), int(cap_pairs), int(cap_rows))
 			return plan, st
 		sparse = plan.sparse
 		fused = plan.fused

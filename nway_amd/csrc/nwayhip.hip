@@ -34,6 +34,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <type_traits>
 
 #include "nwayhip.h"
 

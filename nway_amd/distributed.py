@@ -322,7 +322,8 @@ class SecondarySplitMatch(object):
 
 	primary: this rank's shard of the primary catalogue (the shards are all-gathered once at set-up)
 	secondaries: list of this rank's SLICES of the secondary catalogues (``error`` may be a scalar)
-	capacity: records per (destination, catalogue) block of the export buffer (None: from the sizes)
+	capacity: records per (destination, catalogue) block of the export buffer (None: a first guess from the sizes, then
+	  what the settling step counted in the fullest block of any rank + 25 %: the exchange ships whole blocks)
 	tuning: development / test knobs of the plan (``_hip.make_params``), normally None
 
 	As in ``ShardedMatch`` the exchange logic only touches the hooks ``_exchange_device``, ``_sync``,
@@ -343,6 +344,8 @@ class SecondarySplitMatch(object):
 		self.device = device
 		self.group = group
 		self.capacity = capacity
+		self.capacity_fixed = capacity  # the caller's choice stays (None: sized by the settling step, _build_plan)
+		self.block_records_used = None
 		self.tuning = tuning
 		self.rank, self.world = world_info(group)
 		self.plan = None
@@ -436,6 +439,7 @@ class SecondarySplitMatch(object):
 		self.bounds_dev = torch.as_tensor(self.bounds).to(self.device)
 		capacity = self.capacity or max(1024, 4 * max(self.primary_sizes) // self.world + 1024)
 		slot_retries = 0
+		tightened = False
 		for attempt in range(8):
 			self.plan = _hip.MatchPlan(sizes, self.params, 65536, cap_rows, self.device, lean=True)
 			if not self.plan.split_capable:
@@ -472,7 +476,18 @@ class SecondarySplitMatch(object):
 			else:
 				flags_any, slot_need = flags, int(st[_hip.ST_SLOT_NEED])
 			if flags_any == 0:
+				# the exchange ships whole blocks: size them by what this settling step counted -- the fullest block of any
+				# rank, a quarter more -- instead of the a-priori guess (5e5 x 1e8 over 8 ranks: 1 MB per peer for 0.2 MB of
+				# records).  A later step that outgrows it is flagged (PAIR_OVERFLOW: the receiver sees count > capacity).
+				used = self._fullest_block()
+				tight = used + (used >> 2) + 64
+				if not tightened and self.capacity_fixed is None and tight * 3 < capacity * 2:
+					tightened = True
+					capacity = tight
+					self._drop_plan()
+					continue
 				self.status = st
+				self.block_records_used = used
 				return
 			# the plan and what points into its buffers go before anything is raised or retried
 			self._drop_plan()
@@ -491,6 +506,18 @@ class SecondarySplitMatch(object):
 			if flags_any & _hip.FLAG_ROW_OVERFLOW:
 				cap_rows = min(cap_rows * 2, (1 << 31) - 4096)
 		raise _hip.NwayHipError('secondary-split mode: capacities could not be settled')
+
+	def _fullest_block(self):
+		"""records in the fullest (source, catalogue) block any rank received in the last step (header record of every block:
+		sparse.inc, ExportRec), the same number on every rank"""
+		import torch
+		k1 = len(self.secondary_slices)
+		words = self.imported.view(torch.int32)[:self.world * k1 * (self.capacity + 1) * 8]
+		heads = words.view(self.world * k1, (self.capacity + 1) * 8)[:, 0]
+		m = heads.max().to(torch.int64).reshape(1)
+		if self.world > 1:
+			_dist().all_reduce(m, op=_dist().ReduceOp.MAX, group=self.group)
+		return int(m.item())
 
 	def _drop_plan(self):
 		"""close the plan and forget everything that points into its buffers"""

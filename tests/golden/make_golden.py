@@ -697,6 +697,55 @@ if __name__ == '__main__' and ('kway' in sys.argv[1:] or not sys.argv[1:]):
 	gen_kway()
 
 
+def gen_kmulti():
+	"""5- and 6-way matches with SEVERAL LINKS PER CATALOGUE for a few hundred primaries -- the case the one-lane tuple walk
+	of the HIP path got wrong for three rounds (two links in each of two or more catalogues with k >= 5) while the tiny
+	kway tables passed.  Primaries on a lattice 72 arcsec apart (radius 10 arcsec: groups never touch); every secondary
+	catalogue gives a primary 0, 1 or 2 sources (probabilities 0.25 / 0.35 / 0.4) scattered by N(0, 2.5 arcsec) per axis, so that
+	some pairs of secondaries exceed the radius; plus a sprinkle of field sources.  The reference's nway_match runs these
+	in seconds (nwaylib/__init__.py:31-120)."""
+	out = {}
+	for tag, k, nprim, radius, comp, seed in (('m5', 5, 320, 10., 0.85, 101), ('m6', 6, 180, 10., np.array([1.0, 0.95, 0.9, 0.85, 0.8, 0.75]), 102)):
+		rng = np.random.RandomState(seed)
+		side = int(np.ceil(np.sqrt(nprim)))
+		gx, gy = np.meshgrid(np.arange(side), np.arange(side))
+		pdec = 20.0 + gy.ravel()[:nprim] * 0.02
+		pra = 130.0 + gx.ravel()[:nprim] * 0.02 / np.cos(np.radians(20.3))
+		span = side * 0.02
+		area = (span + 0.02)**2
+		tabs = [cat('T0', pra, pdec, rng.uniform(0.8, 2.0, size=nprim), area)]
+		multi = np.zeros(nprim, dtype=int)
+		for c in range(1, k):
+			ra, dec = [], []
+			for i in range(nprim):
+				m = rng.choice(3, p=[0.25, 0.35, 0.4])
+				multi[i] += (m == 2)
+				for _ in range(m):
+					dec.append(pdec[i] + rng.normal(0, 2.5) / 3600.)
+					ra.append(pra[i] + rng.normal(0, 2.5) / 3600. / np.cos(np.radians(pdec[i])))
+			nfield = nprim // 2
+			ra += list(rng.uniform(pra.min() - 0.005, pra.max() + 0.005, size=nfield))
+			dec += list(rng.uniform(pdec.min() - 0.005, pdec.max() + 0.005, size=nfield))
+			order = rng.permutation(len(ra))  # (catalogue order is not primary order)
+			tabs.append(cat('T%d' % c, np.array(ra)[order], np.array(dec)[order], rng.uniform(0.2, 1.2, size=len(ra)), area))
+		for i, t in enumerate(tabs):
+			out['%s_ra%d' % (tag, i)], out['%s_dec%d' % (tag, i)], out['%s_err%d' % (tag, i)] = t['ra'], t['dec'], t['error']
+		names = [t['name'] for t in tabs]
+		res = run(tabs, radius, comp)
+		out[tag + '_area'] = np.array([area]); out[tag + '_radius'] = np.array([radius]); out[tag + '_completeness'] = np.atleast_1d(comp)
+		out.update(table_arrays(res, names, tag + '_'))
+		out.update(cli_correction_prefixed(ref, tabs, radius, comp, tag + '_'))
+		groups = np.bincount(res[names[0]].values)
+		print('%s: %d rows, ncat %s, largest group %d, primaries with two sources in >= 2 catalogues: %d, %d rows corrected' % (
+			tag, len(res), np.bincount(res['ncat'].values), groups.max(), (multi >= 2).sum(), len(out[tag + '_cli_changed_rows'])))
+		assert (multi >= 2).sum() >= 100
+	save('kmulti', **out)
+
+
+if __name__ == '__main__' and ('kmulti' in sys.argv[1:] or not sys.argv[1:]):
+	gen_kmulti()
+
+
 def script_mag_numerics(tables, radius, completeness, mag_include_radius=None, mag_exclude_radius=None, minprob=0.9,
 		prob_ratio_secondary=0.5):
 	"""What the SCRIPT computes with ``--mag T:col auto`` for every magnitude column of ``tables``:

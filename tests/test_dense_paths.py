@@ -266,9 +266,10 @@ def test_dense_three_way_field_with_tens_of_links_per_catalogue():
 
 @pytest.mark.parametrize('k', [5, 6])
 def test_many_catalogues_with_two_links_in_several_of_them(k):
-	"""k_tailk<K> for K >= 5 (no register copy of a catalogue's first link, a kernel that spills): primaries with two links in
-	two or more catalogues once got the first link's separation from the second (round 3, found by tools/dev/soak_mid.py with
-	SOAK_KMAX=6) -- mid-size, because the tiny many-catalogue cases of test_hip_fuzz.py never showed it"""
+	"""five and six catalogues with two links in several of them for a few hundred primaries -- the input on which the one-lane
+	walk k_tailk<K >= 5> (313-512 VGPRs, scratch) carried the first link's separation from the second through rounds 1-3 (found by
+	tools/dev/soak_mid.py with SOAK_KMAX=6; the tiny many-catalogue cases of test_hip_fuzz.py never showed it).  Since round 4 the
+	walk is compiled for three and four catalogues only: more take the sparse front with the general back end"""
 	import nway_amd as nw
 	from nway_amd import _hip
 	rng = np.random.default_rng(40 + k)
@@ -283,7 +284,7 @@ def test_many_catalogues_with_two_links_in_several_of_them(k):
 	import nway_oracle_c as orc_c
 	names = [x['name'] for x in tabs]
 	t, status = hip_table(nw, tabs, 5.0, 0.9)
-	assert int(status[1]) == 0 and t['_desc']['tail'] == 'sparsek' and t['_path'] == _hip.PATH_SPARSE
+	assert int(status[1]) == 0 and t['_desc']['tail'] == 'hybrid' and t['_path'] == _hip.PATH_HYBRID and t['_desc']['link_slots'] == 8
 	compare(t, orc_c.nway_match(tabs, 5.0, 0.9, correction='api'), names)
 	g, _ = hip_table(nw, tabs, 5.0, 0.9, link_slots=-1)
 	assert g['_path'] == 0

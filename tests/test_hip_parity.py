@@ -39,7 +39,7 @@ def run(nw, tables, radius, completeness, **kw):
 def test_loaded_native_library(nw):
 	from nway_amd import _hip
 	lib = _hip.load()
-	assert lib.nwayhip_version() == 1
+	assert lib.nwayhip_version() == _hip.ABI_VERSION
 	assert _hip.device_count() >= 1
 
 
@@ -210,6 +210,33 @@ def test_four_and_five_way_golden(nw):
 		np.testing.assert_array_equal(tc['match_flag'], to['match_flag'])
 		for c in ('dist_post', 'p_single', 'prob_has_match', 'prob_this_match'):
 			np.testing.assert_allclose(tc[c], to[c], rtol=RTOL, atol=ATOL, err_msg=c)
+
+
+@pytest.mark.parametrize('path', ['default', 'hybrid24', 'general'])
+def test_five_and_six_way_with_several_links_per_catalogue_golden(nw, path):
+	"""reference-generated tables (tests/golden/make_golden.py: gen_kmulti) with two sources in two or more catalogues for a
+	few hundred primaries, groups of up to 243 rows -- the input class on which the one-lane walk k_tailk<5>, k_tailk<6> carried
+	wrong separations through rounds 1-3 while the tiny kway tables passed (those instantiations are gone: five or more
+	catalogues take the sparse front with the general back end): the plan's own choice (8 slots), 24 slots forced, and the
+	general path; index columns, ncat, match_flag equal, every
+	separation column and probability within the contract; the script's correction loop as well"""
+	from nway_amd import _hip
+	from test_oracle_golden import kmulti_cases
+	tuning = dict(default=None, hybrid24=dict(link_slots=24), general=dict(link_slots=-1))[path]
+	for tag, names, tabs, radius, comp, g in kmulti_cases():
+		res = nw.run_match(tabs, radius, comp, tuning=tuning, logger=nw.NullOutputLogger())
+		desc = res.plan.description
+		res.plan.close()
+		if path == 'general':
+			assert desc['path'] == 0, desc
+		else:
+			assert desc['path'] == _hip.PATH_HYBRID and desc['tail'] == 'hybrid' and desc['link_slots'] == (8 if path == 'default' else 24), desc
+		t = run(nw, tabs, radius, comp, tuning=tuning)
+		assert_table_matches(t, g, tag + '_', names)
+		tc = run(nw, tabs, radius, comp, unrelated_associations='cli', tuning=tuning)
+		delta = tc['dist_bayesfactor'] - tc['dist_bayesfactor_uncorrected']
+		np.testing.assert_array_equal(np.flatnonzero(delta != 0), g[tag + '_cli_changed_rows'])
+		np.testing.assert_allclose(delta[delta != 0], g[tag + '_cli_correction'], rtol=1e-6)
 
 
 def test_randomized_configurations_golden(nw, tmp_path, monkeypatch):

@@ -179,6 +179,31 @@ def test_four_and_five_way_with_script_correction():
 			assert_table_matches(ts, g, tag + '_script_', names, **TIGHT)
 
 
+def kmulti_cases():
+	g = golden('kmulti')
+	for tag, k in (('m5', 5), ('m6', 6)):
+		names = ['T%d' % i for i in range(k)]
+		tabs = [cat(names[i], g['%s_ra%d' % (tag, i)], g['%s_dec%d' % (tag, i)], g['%s_err%d' % (tag, i)], g[tag + '_area'][0]) for i in range(k)]
+		comp = g[tag + '_completeness']
+		yield tag, names, tabs, float(g[tag + '_radius'][0]), (float(comp[0]) if len(comp) == 1 else comp), g
+
+
+def test_five_and_six_way_with_several_links_per_catalogue():
+	"""the reference's nway_match on 5- and 6-way tables where a few hundred primaries have two sources in two or more
+	catalogues (groups of up to 243 rows): both oracles, also the script's correction loop"""
+	for tag, names, tabs, radius, comp, g in kmulti_cases():
+		assert np.bincount(g[tag + '_idx'][:, 0]).max() >= 90
+		for oracle in (orc, orc_c):
+			t = oracle.nway_match(tabs, radius, comp)
+			# (1e-10: a last-bit difference of a sine or cosine -- numpy's vector loops against its scalar ones, glibc in the C
+			# restatement -- is 5e-12 of a separation of a few arcsec)
+			assert_table_matches(t, g, tag + '_', names, rtol=1e-10, atol=1e-13)
+			tc = oracle.nway_match(tabs, radius, comp, correction='cli')
+			delta = tc['dist_bayesfactor'] - tc['dist_bayesfactor_uncorrected']
+			np.testing.assert_array_equal(np.flatnonzero(delta != 0), g[tag + '_cli_changed_rows'])
+			np.testing.assert_allclose(delta[delta != 0], g[tag + '_cli_correction'], rtol=1e-9)
+
+
 def test_randomized_configurations():
 	"""35 small random configurations run through the reference (flat cells and its HEALPix
 	branch at the poles, the seam and high declination; k = 2..4; completeness, ratio, min_prob)"""

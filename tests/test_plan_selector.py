@@ -171,3 +171,9 @@ def test_four_lanes_per_primary_of_a_sparse_three_way_field():
 	assert describe(n, 0.0005, link_slots=1)['tail'] == 'sparsek'   # (its lanes read two slots of every primary)
 	assert describe(n, 0.0005, correction=_hip.CORRECTION_CLI)['tail'] == 'quad3'
 	assert describe(n[:2], 0.0005)['tail'] == 'sparse2' and describe(n + [1000000], 0.0005)['tail'] == 'sparsek'
+	# the one-lane walk: three and four catalogues (four with the script's correction: the general back end); five or more: hybrid
+	n4 = n + [1000000]
+	assert describe(n4, 0.0005, correction=_hip.CORRECTION_CLI)['tail'] == 'hybrid'
+	five = describe(n4 + [1000000], 0.0005)
+	assert (five['tail'], five['path'], five['link_slots'], five['split_capable']) == ('hybrid', 2, 8, 0)
+	assert describe(n4 + [1000000] * 4, 0.0005)['tail'] == 'hybrid'

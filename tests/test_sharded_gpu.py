@@ -109,7 +109,7 @@ def test_primary_shards_on_device(tmp_path, k, flat, cut):
 def test_bench_under_torchrun_two_ranks(tmp_path, scaling):
 	"""bench.py as the driver launches it for N > 1 (one process per rank, torch.distributed.run), here
 	with two gloo ranks on the one GPU and a reduced workload: the JSON line of rank 0"""
-	env = dict(os.environ, NWAY_BENCH_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+	env = dict(os.environ, NWAY_BENCH_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0', NWAY_BENCH_EXTRAS='0')
 	cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
 		'--master-port', str(free_port()), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '5', '--warmup', '2', '--prewarm', '3',
 		'--n-primary', '20000', '--n-secondary', '2000000', '--scaling', scaling]
@@ -204,7 +204,7 @@ def test_rccl_is_there_and_carries_the_engines_collectives(tmp_path):
 def test_bench_one_rank_through_rccl(scaling, comm):
 	"""bench.py's N > 1 code -- engines, barriers, the MAX over ranks -- with ONE rank on the real backend ("nccl" = RCCL):
 	NWAY_BENCH_FORCE_DIST=1 (the driver's 2 / 4 / 8-GPU runs take the same lines with more ranks)"""
-	env = dict(os.environ, NWAY_BENCH_FORCE_DIST='1', HSA_ENABLE_IPC_MODE_LEGACY='0', MASTER_PORT=str(free_port()))
+	env = dict(os.environ, NWAY_BENCH_FORCE_DIST='1', HSA_ENABLE_IPC_MODE_LEGACY='0', MASTER_PORT=str(free_port()), NWAY_BENCH_EXTRAS='0')
 	cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '5', '--warmup', '2', '--prewarm', '3', '--n-primary', '20000',
 		'--n-secondary', '2000000', '--scaling', scaling, '--cpu-sample', '0', '--comm', comm]
 	res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, timeout=600, env=env, cwd=ROOT)
@@ -213,3 +213,57 @@ def test_bench_one_rank_through_rccl(scaling, comm):
 	assert out['n_gpus'] == 1 and out['scaling'] == scaling and 20000 * 1.7 < out['config']['rows_per_step'] < 20000 * 1.9
 	assert out['config']['exchanges'].startswith('nwayhip_comm' if comm == 'rccl' else 'torch')
 	assert out['config']['parallelism'].startswith('secondary-stream' if scaling == 'strong' else 'primary-row')
+
+
+EXTRA_JOBS = ['c3s_split', 'c4s_rows', 'c5_rows', 'c5_split']
+
+
+def check_extra_configs(out, world, comms, scale):
+	"""bench.py's extra_configs block: the fixed-size jobs BASELINE names for several GPUs, one record per job and carrier"""
+	recs = out['extra_configs']
+	assert [(r['job'], r['exchanges'].split(' ')[0]) for r in recs] == [(j, c) for j in EXTRA_JOBS for c in comms], [(r['job'], r['exchanges']) for r in recs]
+	for r in recs:
+		assert 'error' not in r, r
+		assert r['n_gpus'] == world and r['ranks_seen'] == world and r['flags'] == 0 and r['scaling'] == 'strong'
+		assert r['ms_per_step'] > 0 and r['value'] > 0 and 0 < r['pass_frac'] < 1 and 0 < r['rank0_pass_frac'] < 1
+		n0 = r['sizes'][0]
+		assert n0 == max(int({'c3s_split': 1e5, 'c4s_rows': 1e5, 'c5_rows': 5e5, 'c5_split': 5e5}[r['job']] * scale), 8 * world)
+		# rows of the WHOLE job: every primary once + its counterparts (80 %; the 3-way job: (1 + 0.8)(1 + 0.6) rows per primary)
+		per = 2.88 if r['job'] == 'c4s_rows' else 1.8
+		assert 0.9 * per * n0 < r['rows'] < 1.1 * per * n0 + 50, r
+		if r['job'].endswith('split'):
+			assert r['mode'].startswith('secondary-stream') and 0 < r['exchange_block_records_used'] <= r['exchange_block_records']
+			assert r['exchange_block_records'] <= 2 * r['exchange_block_records_used'] + 64   # (sized by the settling step)
+		else:
+			assert r['mode'].startswith('primary-row') and r['setup_exchange_bytes'] >= 16 * sum(r['sizes'][1:])
+
+
+def test_bench_extra_configs_two_ranks(tmp_path):
+	"""the block the first multi-GPU run of the driver will carry: two gloo ranks on the one GPU,
+	catalogue sizes scaled to 2 %"""
+	env = dict(os.environ, NWAY_BENCH_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0', NWAY_BENCH_EXTRA_SCALE='0.02')
+	cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+		'--master-port', str(free_port()), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '4', '--warmup', '2', '--prewarm', '3',
+		'--n-primary', '20000', '--n-secondary', '2000000']
+	res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, timeout=900, env=env, cwd=ROOT)
+	assert res.returncode == 0, res.stderr[-3000:]
+	line = [l for l in res.stdout.splitlines() if l.startswith('{')][-1]
+	out = json.loads(line)
+	assert out['n_gpus'] == 2 and out['scaling'] == 'weak'
+	check_extra_configs(out, 2, ['torch.distributed'], 0.02)
+	keep = os.path.join(ROOT, 'gpurun_out')
+	if os.path.isdir(keep):
+		with open(os.path.join(keep, 'bench_x2_extras.json'), 'w') as f:
+			f.write(line + '\n')
+
+
+def test_bench_extra_configs_one_rank_both_carriers():
+	"""the same block with ONE rank on the real backend: every job through torch.distributed AND through the library's own
+	RCCL calls (nwayhip_comm_*)"""
+	env = dict(os.environ, NWAY_BENCH_FORCE_DIST='1', HSA_ENABLE_IPC_MODE_LEGACY='0', MASTER_PORT=str(free_port()), NWAY_BENCH_EXTRA_SCALE='0.02')
+	cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '4', '--warmup', '2', '--prewarm', '3', '--n-primary', '20000',
+		'--n-secondary', '2000000', '--cpu-sample', '0']
+	res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, timeout=900, env=env, cwd=ROOT)
+	assert res.returncode == 0, res.stderr[-3000:]
+	out = json.loads([l for l in res.stdout.splitlines() if l.startswith('{')][-1])
+	check_extra_configs(out, 1, ['torch.distributed', 'nwayhip_comm_*'], 0.02)

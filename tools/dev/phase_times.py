@@ -63,6 +63,19 @@ for k, (kname, labels) in names.items():
 		if lab is not None and (fused or lab != 'barrier passed'):
 			print('    %-26s %7.2f | %7.2f' % (lab, rel[:, :, i].mean(), rel[:, :, i].max(axis=1).mean()))
 t = buf.cpu().numpy().reshape(3, BLOCKS, STAMPS).astype(np.float64) * 0.01
+# distribution over the workgroups of the last run (the scan of the tail waits for its SLOWEST predecessor)
+for k, (kname, labels) in names.items():
+	used = t[k][:, 0] > 0
+	t0 = t[k][used][:, 0].min()
+	for i, lab in enumerate(labels):
+		if lab is None or i >= t[k].shape[1]:
+			continue
+		v = t[k][used][:, i] - t0
+		if (t[k][used][:, i] > 0).sum() == 0:
+			continue
+		order = np.argsort(v)
+		print('%-14s %-26s p10 %6.2f p50 %6.2f p90 %6.2f p99 %6.2f max %6.2f  slowest workgroups %s' % (kname[:14], lab, np.percentile(v, 10), np.percentile(v, 50),
+			np.percentile(v, 90), np.percentile(v, 99), v.max(), list(np.flatnonzero(used)[order[-6:]])))
 first = t[1][t[1][:, 0] > 0][:, 0].min() if fused else t[0][t[0][:, 0] > 0][:, 0].min()
 print('last run: %s start -> sweep start %.2f us, sweep start -> tail start %.2f us, tail start -> tail end %.2f us' % (
 	'sweep' if fused else 'register', t[1][t[1][:, 0] > 0][:, 0].min() - first, t[2][t[2][:, 0] > 0][:, 0].min() - t[1][t[1][:, 0] > 0][:, 0].min(),

@@ -9,6 +9,24 @@ import json
 import os
 import sys
 
+import hashlib
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def kernel_source_hash():
+	"""sha256 over the kernel sources (nway_amd/csrc/*.inc, *.hip, include/nwayhip.h), in name order: what bench.py compares with the
+	tree it runs in, so that a counter summary of an OLDER build is recognised as such"""
+	h = hashlib.sha256()
+	files = sorted(glob.glob(os.path.join(ROOT, 'nway_amd', 'csrc', '*.inc')) + glob.glob(os.path.join(ROOT, 'nway_amd', 'csrc', '*.hip'))) + [
+		os.path.join(ROOT, 'include', 'nwayhip.h')]
+	for f in files:
+		h.update(os.path.basename(f).encode())
+		h.update(open(f, 'rb').read())
+	return h.hexdigest()[:16]
+
+
 src, dst, tag = sys.argv[1], sys.argv[2], sys.argv[3]
 n_secondary = int(sys.argv[4]) if len(sys.argv) > 4 else 10000000
 os.makedirs(dst, exist_ok=True)
@@ -66,5 +84,12 @@ if sweep:
 		algorithmic_bytes_per_launch=stream, avg_launch_us=kernel_avg.get(k),
 		correction='FETCH_SIZE KiB*1024 + half of the 16 B/lane coalesced stream (gfx950 reports that half only; the gathers of the '
 			'kernel are counted in full), WRITE_SIZE KiB*1024')
+	# the build these counters belong to (run this script in the tree that was measured, before editing the kernels)
+	rec['kernel_source_sha16'] = kernel_source_hash()
+	try:
+		rec['git_head'] = subprocess.check_output(['git', '-C', ROOT, 'rev-parse', '--short=12', 'HEAD'], universal_newlines=True).strip()
+		rec['git_dirty'] = bool(subprocess.check_output(['git', '-C', ROOT, 'status', '--porcelain', '--', 'nway_amd/csrc', 'include'], universal_newlines=True).strip())
+	except Exception:
+		rec['git_head'], rec['git_dirty'] = None, None
 	json.dump(rec, open(os.path.join(dst, 'sweep_traffic.json'), 'w'), indent=1)
 	print(json.dumps(rec))
