@@ -165,8 +165,12 @@ def test_four_way_with_the_scripts_correction_fused_and_on_the_general_back_end(
 		b['ra'][:m] = prim['ra'][:m]
 		b['dec'][:m] = np.clip(prim['dec'][:m] + rng.normal(0, 0.3, size=m) / 3600., -90, 90)
 		tabs.append(dict(b, name=name, error=sig * np.ones(n)))
+	# (round 4: k_tailk<4, true> -- 292 VGPRs and 344 bytes of scratch -- is no longer compiled: four catalogues with the script's
+	# correction take k_correct behind the general back end; without the correction the one-lane walk k_tailk<4, false>)
 	t = both_paths(nw, tabs, 10.0, correction=_hip.CORRECTION_CLI)
-	assert t['_path'] == _hip.PATH_SPARSE   # k_tailk<4, true>: one lane per primary corrects its rows
+	assert t['_path'] == _hip.PATH_HYBRID
+	t = both_paths(nw, tabs, 10.0)
+	assert t['_path'] == _hip.PATH_SPARSE and t['_desc']['tail'] == 'sparsek'
 	t = both_paths(nw, tabs, 10.0, correction=_hip.CORRECTION_CLI, tuning=dict(disable=_hip.DISABLE_FUSED_CORRECTION))
 	assert t['_path'] == _hip.PATH_HYBRID   # the same with k_correct behind the general back end
 	# a dense 4-way field with the correction: hybrid

@@ -41,7 +41,7 @@ torch.cuda.synchronize()
 fused = False
 names = {0: ('k_register_x', ['start', None, 'claims + stores landed', 'end']),
 	1: ('k_sweep', ['start', 'bitmap in LDS', 'wave 0 done streaming', 'all waves done', 'probes landed', 'end', 'barrier passed']),
-	2: ('k_tail2', ['start', 'cnt/slot/sigma landed', 'block scan', 'lookback', 'rows landed', 'group stats landed'])}
+	2: ('k_tail2', ['start', 'cnt/slot/sigma landed', 'block scan', 'lookback', 'rows landed', 'group stats landed', 'items set up', 'separations done'])}
 if fused:
 	names[0] = ('registration inside the sweep launch (times since the first SWEEP workgroup started)', [None, None, 'claims + stores landed', 'announced'])
 acc = {}
