@@ -224,7 +224,9 @@ int32_t nwayhip_plan_path(const nwayhip_plan* plan);
 #define NWAYHIP_TAIL_QUAD3 6             /* k_tail3q: k = 3, four lanes per primary */
 int nwayhip_plan_describe(const nwayhip_plan* plan, int32_t* h_out);
 /* 1 if the plan can run the secondary-split mode below (sparse front with the tails
- * NWAYHIP_TAIL_SPARSE2 / NWAYHIP_TAIL_DENSE2 / NWAYHIP_TAIL_SPARSEK), else 0 */
+ * NWAYHIP_TAIL_SPARSE2 / NWAYHIP_TAIL_DENSE2 / NWAYHIP_TAIL_SPARSEK / NWAYHIP_TAIL_QUAD3), else 0.  With NWAYHIP_TAIL_QUAD3 a
+ * run may come back with NWAYHIP_FLAG_QUAD_DEEP: every caller of the split entry points repeats it with
+ * NWAYHIP_DISABLE_QUAD3, as nway_amd/distributed.py does */
 int32_t nwayhip_plan_split_capable(const nwayhip_plan* plan);
 /* Enqueue the whole pipeline on `stream`.  d_status: device int64[NWAYHIP_STATUS_WORDS].
  * The workspace's contents may be arbitrary the first time a plan sees it (the plan clears what

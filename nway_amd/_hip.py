@@ -228,6 +228,7 @@ def _upload_large(a, out):
 
 
 _download_stage = {}
+_download_lock = threading.Lock()  # (the staging buffers are shared: two threads downloading at once would overwrite each other's)
 
 
 def to_host(tensor):
@@ -239,14 +240,15 @@ def to_host(tensor):
 	if not tensor.is_cuda or nbytes < (64 << 10) or os.environ.get('NWAY_DOWNLOAD', '') == 'direct':
 		return tensor.cpu().numpy()
 	src = tensor.contiguous()
-	stage = _download_stage.get(src.dtype)
-	if stage is None or stage.numel() < src.numel():
-		stage = t.empty(max(src.numel(), (4 << 20) // src.element_size()), dtype=src.dtype, pin_memory=True)
-		_download_stage[src.dtype] = stage
-	view = stage[:src.numel()]
-	view.copy_(src.reshape(-1), non_blocking=True)
-	t.cuda.current_stream(src.device).synchronize()
-	return view.numpy().reshape(tuple(src.shape)).copy()
+	with _download_lock:
+		stage = _download_stage.get(src.dtype)
+		if stage is None or stage.numel() < src.numel():
+			stage = t.empty(max(src.numel(), (4 << 20) // src.element_size()), dtype=src.dtype, pin_memory=True)
+			_download_stage[src.dtype] = stage
+		view = stage[:src.numel()]
+		view.copy_(src.reshape(-1), non_blocking=True)
+		t.cuda.current_stream(src.device).synchronize()
+		return view.numpy().reshape(tuple(src.shape)).copy()
 
 
 def to_device(array, device, dtype=None):
@@ -372,7 +374,11 @@ class RcclComm(object):
 	def allgatherv(self, tensor, counts):
 		"""every rank's 1-D float64 slice -> the whole column (rank order) on every GPU; counts: rows of every rank"""
 		t = torch()
+		if tensor.dtype != t.float64:
+			raise TypeError('RcclComm.allgatherv moves float64 columns, got %s' % tensor.dtype)
 		full = t.empty(int(sum(counts)), dtype=t.float64, device=self.device)
+		if full.numel() == 0:
+			return full  # (nothing to move: a NULL receive buffer is not an argument the library accepts)
 		arr = (ctypes.c_int64 * self.world)(*[int(c) for c in counts])
 		src = tensor.contiguous()
 		check(self.lib.nwayhip_comm_allgatherv_f64(self.handle, ptr(src) if int(counts[self.rank]) > 0 else None, arr, ptr(full), current_stream_ptr(self.device)))
@@ -587,10 +593,13 @@ class MatchPlan(object):
 			if nf:
 				rows = t.tensor([self.f64_row[c] for c in f64_columns], dtype=t.int64, device=self.device)
 				t.index_select(self.block_f64[:, :n], 0, rows, out=pack[(ni + ns) * n:].view(t.float64).view(nf, n))
-			host = t.empty(words, dtype=t.int64, pin_memory=True)
-			host.copy_(pack, non_blocking=True)
-			t.cuda.current_stream(self.device).synchronize()
-		flat = host.numpy()
+			if os.environ.get('NWAY_DOWNLOAD', '') == 'direct':
+				flat = pack.cpu().numpy()  # (development: the runtime's own pageable path, tools/dev/fault_study.sh)
+			else:
+				host = t.empty(words, dtype=t.int64, pin_memory=True)
+				host.copy_(pack, non_blocking=True)
+				t.cuda.current_stream(self.device).synchronize()
+				flat = host.numpy()
 		if os.environ.get('NWAY_DOWNLOAD', '') == 'copy':
 			flat = flat.copy()  # (pageable memory of the caller's own)
 		idx = [flat[c * n:(c + 1) * n] for c in range(ni)]
@@ -799,4 +808,5 @@ def run_plan(sizes, params, catalogues, cap_pairs, cap_rows, device, max_retries
 			cap_rows = min(cap_rows, CAPACITY_LIMIT)
 		if cap_pairs > CAPACITY_LIMIT:
 			raise NwayHipError('more than 2^31 links: split the primary catalogue')
-		torch().cuda.empty_cache()
+		if os.environ.get('NWAY_NO_EMPTY_CACHE', '') != '1':  # (development: tools/dev/fault_study.sh tells the variants apart)
+			torch().cuda.empty_cache()

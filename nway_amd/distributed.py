@@ -9,8 +9,10 @@ the secondary densities only (nu_0 cancels against nu+_0 = nu_0, __init__.py:214
 a shard's rows are bit-identical to the same rows of the unsharded run.
 
 The one exchange step is the distribution of the secondary catalogues: each rank loads a
-slice and an all-gatherv (one RCCL all-gather of equally padded pieces) leaves the
-full ra / dec / error columns resident on every GPU.  It happens once per catalogue, not
+slice and an all-gatherv leaves the full ra / dec / error columns resident on every GPU --
+through torch.distributed as ONE RCCL all-gather of equally padded pieces (the default), or,
+with ``comm='rccl'``, through the library's own RCCL calls behind the C ABI as one group of
+broadcasts, no padding (csrc/comm.inc: nwayhip_comm_allgatherv_f64).  It happens once per catalogue, not
 once per primary batch; ``ShardedMatch.setup`` times it separately.  No collective is on
 the per-batch path; the host concatenates per-rank tables in rank order when a global
 table is wanted.
