@@ -276,17 +276,35 @@ def extra_configs(args, world, rank, device, dist, backend):
 	comms = ['torch'] + (['rccl'] if backend == 'nccl' else [])
 	steps, warm = min(args.steps, 20), min(max(args.warmup, 2), 5)
 	records = []
+	budget_s = float(os.environ.get('NWAY_BENCH_EXTRA_BUDGET', '420'))  # the whole block is skipped job by job once this is spent
+	t_start = time.perf_counter()
+
+	def agreed(ok):
+		"""the same decision on every rank (a rank that failed alone would leave the others in a collective)"""
+		flag = torch.tensor([1 if ok else 0], dtype=torch.int64, device=device)
+		dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+		return bool(flag.item())
 	for name, mode, sizes, radius in jobs:
 		if only and name not in only.split(','):
 			continue
+		if not agreed(time.perf_counter() - t_start < budget_s):
+			records.append(dict(job=name, skipped='time budget of the extra configurations (%g s) spent' % budget_s))
+			continue
 		local = [distributed.shard_bounds(n, world) for n in sizes]
 		mine = [int(b[rank + 1] - b[rank]) for b in local]
-		if len(sizes) == 2:
-			tabs = list(make_workload(mine[0], mine[1], args.seed + 77 + 1000 * rank))
-		else:
-			tabs = make_workload3(mine[0], mine[1], mine[2], args.seed + 77 + 1000 * rank)
-		for t, n in zip(tabs, sizes):
-			t['area'] = SKY_AREA  # (of the whole catalogue: the engines take the densities from the global sizes)
+		tabs, gen_error = None, None
+		try:
+			if len(sizes) == 2:
+				tabs = list(make_workload(mine[0], mine[1], args.seed + 77 + 1000 * rank))
+			else:
+				tabs = make_workload3(mine[0], mine[1], mine[2], args.seed + 77 + 1000 * rank)
+			for t, n in zip(tabs, sizes):
+				t['area'] = SKY_AREA  # (of the whole catalogue: the engines take the densities from the global sizes)
+		except Exception as e:
+			gen_error = '%s: %s' % (type(e).__name__, e)
+		if not agreed(gen_error is None):
+			records.append(dict(job=name, error='a rank could not generate its shard: %s' % gen_error))
+			continue
 		for comm in comms:
 			rec = dict(job=name, mode=('secondary-stream slices + candidate routing' if mode == 'split' else 'primary-row shards'),
 				sizes=sizes, radius_arcsec=radius, exchanges=('nwayhip_comm_* (RCCL behind the C ABI)' if comm == 'rccl' else 'torch.distributed (%s)' % backend),

@@ -2,7 +2,7 @@
 neighbours per primary from 0.01 to a few, patches and the whole sky, k = 2..4) against the C
 oracle -- covers the fused sparse kernels, their fall-back and the general path at sizes where
 workgroup regions, scans and look-back chains are long
-    python tools/dev/soak_mid.py 0 40        (on the GPU box; SOAK_KMAX=6 for up to six catalogues)
+    python tools/dev/soak_mid.py 0 40        (on the GPU box; up to SOAK_KMAX = 8 catalogues by default since round 4: the k >= 5 failure of round 3 hid behind a default of 4)
 """
 import os
 import sys
@@ -20,7 +20,7 @@ lo, hi = int(sys.argv[1]), int(sys.argv[2])
 bad, t0, rows = [], time.time(), 0
 for seed in range(lo, hi):
 	rng = np.random.default_rng(5000 + seed)
-	k = int(rng.integers(2, int(os.environ.get('SOAK_KMAX', '4')) + 1))
+	k = int(rng.integers(2, int(os.environ.get('SOAK_KMAX', '8')) + 1))
 	n0 = int(10 ** rng.uniform(3, 4.7))
 	radius = float(rng.choice([2.0, 5.0, 10.0, 20.0]))
 	lam = 10 ** rng.uniform(-2, 0.7 if k == 2 else (0.3 if k < 5 else -0.5))     # chance neighbours per primary and catalogue
