@@ -10,7 +10,7 @@ for r in $(seq 1 $R); do
 	for n in "$@"; do
 		base=${n%%+*}; extra=""; [ "$base" != "$n" ] && extra="NWAYHIP_DEV=1 ${n#*+}"   # name+VAR=value: a development switch of the library
 		lib=$ROOT/tools/dev/bin/lib_$base.so; [ "$base" = tree ] && lib=$ROOT/nway_amd/csrc/libnwayhip.so
-		env $extra NWAYHIP_LIBRARY=$lib python bench.py --steps 100 --warmup 5 --cpu-sample 0 --two-pipelines 0 --profile-stages 2> /dev/null | tail -1 > gpurun_out/ab/$n.$r.json
+		env $extra NWAYHIP_LIBRARY=$lib timeout 150 python bench.py --steps 100 --warmup 5 --cpu-sample 0 --two-pipelines 0 --profile-stages 2> /dev/null | tail -1 > gpurun_out/ab/$n.$r.json
 	done
 done
 python - "$@" <<'PY'

@@ -38,12 +38,12 @@ plan, st = _hip.run_plan(sizes, params, cats, cap_pairs, cap_rows, dev, lean=Tru
 for _ in range(5):
 	plan.enqueue(cats)
 torch.cuda.synchronize()
-fused = False
+fused = os.environ.get('NWAYHIP_FUSED_FRONT', '0') == '1'  # (front.inc: the registration inside the sweep launch)
 names = {0: ('k_register_x', ['start', None, 'claims + stores landed', 'end']),
-	1: ('k_sweep', ['start', 'bitmap in LDS', 'wave 0 done streaming', 'all waves done', 'probes landed', 'end', 'barrier passed']),
+	1: ('k_sweep', ['start', 'bitmap in LDS', 'wave 0 done streaming', 'all waves done', 'probes landed', 'end', 'barrier passed', 'parked tiles tested']),
 	2: ('k_tail2', ['start', 'cnt/slot/sigma landed', 'block scan', 'lookback', 'rows landed', 'group stats landed', 'items set up', 'separations done'])}
 if fused:
-	names[0] = ('registration inside the sweep launch (times since the first SWEEP workgroup started)', [None, None, 'claims + stores landed', 'announced'])
+	names[0] = ('registration inside the sweep launch (times since the first SWEEP workgroup started)', [None, 'slice parked (all waves)', 'claims + stores landed', 'announced'])
 acc = {}
 for rep in range(10):
 	buf.zero_()
@@ -60,13 +60,14 @@ for k, (kname, labels) in names.items():
 	rel = np.stack([a for a, _ in acc[k]])  # reps x blocks x stamps
 	print('%s: %d workgroups; us since the first workgroup started (mean over workgroups | latest workgroup), mean of 10 runs' % (kname, acc[k][0][1]))
 	for i, lab in enumerate(labels):
-		if lab is not None and (fused or lab != 'barrier passed'):
+		if lab is not None and (fused or lab not in ('barrier passed', 'parked tiles tested')):
 			print('    %-26s %7.2f | %7.2f' % (lab, rel[:, :, i].mean(), rel[:, :, i].max(axis=1).mean()))
 t = buf.cpu().numpy().reshape(3, BLOCKS, STAMPS).astype(np.float64) * 0.01
 # distribution over the workgroups of the last run (the scan of the tail waits for its SLOWEST predecessor)
 for k, (kname, labels) in names.items():
-	used = t[k][:, 0] > 0
-	t0 = t[k][used][:, 0].min()
+	ref = 1 if (fused and k == 0) else k
+	used = t[ref][:, 0] > 0
+	t0 = t[ref][used][:, 0].min()
 	for i, lab in enumerate(labels):
 		if lab is None or i >= t[k].shape[1]:
 			continue
