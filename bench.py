@@ -263,6 +263,8 @@ def extra_configs(args, world, rank, device, dist, backend):
 	  c4s_rows       BASELINE configs[3]: 3-way 1e5 x 1e6 x 1e6, 10", primary rows sharded (ShardedMatch)
 	  c5_rows        BASELINE configs[4]: 5e5 x 1e8, 5", primary rows sharded
 	  c5_split       the same job, secondary stream split
+	  c3s_zones, c4s_zones, c5_zones   the three jobs with BOTH sides sharded by declination zones (ZoneShardedMatch: one
+	                 all-to-all-v of rows at set-up, no collective per step, every rank streams 1/N of the secondaries)
 	Each rank generates ITS shard of the primaries and ITS slices of the secondaries (the counterparts of its primaries lie
 	in its own slices), so no rank ever holds a whole 1e8-row catalogue on the host.  NWAY_BENCH_EXTRA_SCALE (tests) scales
 	every catalogue size."""
@@ -271,7 +273,8 @@ def extra_configs(args, world, rank, device, dist, backend):
 	scale = float(os.environ.get('NWAY_BENCH_EXTRA_SCALE', '1'))
 	sz = lambda n: max(int(n * scale), 8 * world)
 	jobs = [('c3s_split', 'split', [sz(1e5), sz(1e7)], 5.0), ('c4s_rows', 'rows', [sz(1e5), sz(1e6), sz(1e6)], 10.0),
-		('c5_rows', 'rows', [sz(5e5), sz(1e8)], 5.0), ('c5_split', 'split', [sz(5e5), sz(1e8)], 5.0)]
+		('c5_rows', 'rows', [sz(5e5), sz(1e8)], 5.0), ('c5_split', 'split', [sz(5e5), sz(1e8)], 5.0),
+		('c3s_zones', 'zones', [sz(1e5), sz(1e7)], 5.0), ('c4s_zones', 'zones', [sz(1e5), sz(1e6), sz(1e6)], 10.0), ('c5_zones', 'zones', [sz(5e5), sz(1e8)], 5.0)]
 	only = os.environ.get('NWAY_BENCH_EXTRA_ONLY')
 	comms = ['torch'] + (['rccl'] if backend == 'nccl' else [])
 	steps, warm = min(args.steps, 20), min(max(args.warmup, 2), 5)
@@ -305,15 +308,16 @@ def extra_configs(args, world, rank, device, dist, backend):
 		if not agreed(gen_error is None):
 			records.append(dict(job=name, error='a rank could not generate its shard: %s' % gen_error))
 			continue
-		for comm in comms:
-			rec = dict(job=name, mode=('secondary-stream slices + candidate routing' if mode == 'split' else 'primary-row shards'),
+		for comm in (comms if mode != 'zones' else comms[:1]):  # (the zone mode exchanges at set-up only: one carrier)
+			rec = dict(job=name, mode={'split': 'secondary-stream slices + candidate routing', 'rows': 'primary-row shards',
+				'zones': 'declination zones (both sides sharded)'}[mode],
 				sizes=sizes, radius_arcsec=radius, exchanges=('nwayhip_comm_* (RCCL behind the C ABI)' if comm == 'rccl' else 'torch.distributed (%s)' % backend),
 				scaling='strong', n_gpus=world)
 			engine = None
 			try:
 				torch.cuda.synchronize(device)
 				t0 = time.perf_counter()
-				cls = distributed.SecondarySplitMatch if mode == 'split' else distributed.ShardedMatch
+				cls = {'split': distributed.SecondarySplitMatch, 'rows': distributed.ShardedMatch, 'zones': distributed.ZoneShardedMatch}[mode]
 				engine = cls(tabs[0], tabs[1:], radius, args.completeness, device, comm=('rccl' if comm == 'rccl' else None))
 				torch.cuda.synchronize(device)
 				rec['setup_s'] = time.perf_counter() - t0
@@ -346,6 +350,9 @@ def extra_configs(args, world, rank, device, dist, backend):
 					rec['exchange_block_records'] = engine.capacity
 					rec['exchange_block_records_used'] = engine.block_records_used
 					rec['exchange_bytes_per_peer_per_step'] = 32 * (engine.capacity + 1) * (len(sizes) - 1)
+				elif mode == 'zones':
+					rec['setup_exchange_bytes'] = engine.moved_bytes   # (what this rank sent, its own zone's rows included)
+					rec['rank0_zone_sizes'] = [int(c.n) for c in engine.cats]
 				else:
 					rec['setup_exchange_bytes'] = engine.gathered_bytes
 			except Exception as e:  # (a job that does not fit a mode is a record, not the end of the run; every rank raises alike)

@@ -616,3 +616,291 @@ class SecondarySplitMatch(object):
 				continue
 			out[key] = numpy.concatenate([numpy.asarray(g[key]) for g in gathered])
 		return out
+
+
+def exchange_rows(rows, send_counts, group=None):
+	"""all-to-all-v of the ROWS of a 2-D float64 tensor: ``rows`` sorted by destination rank, ``send_counts[r]`` of them for
+	rank r.  Returns what arrived, in source-rank order (the order of the rows of one source is kept).  RCCL: two
+	``all_to_all_single`` (the counts, then the rows with split sizes) on device tensors; gloo: the same calls on host
+	tensors (device tensors -- ranks sharing one GPU in the functional tests -- go through the host)."""
+	import torch
+	dist = _dist()
+	rank, world = world_info(group)
+	if world == 1:
+		return rows
+	on_host = dist.get_backend(group) != 'nccl'
+	dev = rows.device
+	if on_host:
+		rows = rows.cpu()
+	sc = torch.as_tensor([int(c) for c in send_counts], dtype=torch.int64, device=rows.device)
+	rc = torch.zeros_like(sc)
+	dist.all_to_all_single(rc, sc, group=group)
+	recv_counts = [int(c) for c in rc.tolist()]
+	out = torch.empty((sum(recv_counts), rows.shape[1]), dtype=rows.dtype, device=rows.device)
+	dist.all_to_all_single(out, rows.contiguous(), recv_counts, [int(c) for c in send_counts], group=group)
+	return out.to(dev) if on_host else out
+
+
+class ZoneShardedMatch(object):
+	"""ONE job over several GPUs with BOTH sides sharded by declination zones (what BASELINE configs[4] calls pre-bucketing,
+	done across the GPUs): rank z owns the primaries whose declination lies in zone z and holds the secondaries within the
+	match radius of that zone -- a great-circle separation is at least the difference of the declinations, so every
+	counterpart of an owned primary is there.  The catalogues are redistributed ONCE at set-up (an all-to-all-v of rows:
+	every source travels to one rank, the secondaries inside the seams to two -- an eighth of what the all-gatherv of
+	``ShardedMatch`` moves to every rank); no collective is on the per-step path, and a step streams 1/N of the
+	secondaries instead of all of them (``ShardedMatch``) without registering all primaries on every rank or routing
+	candidates between the ranks every step (``SecondarySplitMatch``).  Zone edges: quantiles of the declinations of the
+	largest secondary catalogue (a histogram summed over the ranks), so every rank streams the same number of sources.
+
+	Every row of the table belongs to one primary, its values depend on that primary, its candidates and the densities of
+	the WHOLE catalogues only: a rank's rows are bit-identical to the same rows of the unsharded run.  The rows of a rank are
+	ordered by global primary index (the redistribution keeps the order of the rows of a source rank, and the source ranks
+	hold ascending ranges), with global indices in the index columns; the global table is the concatenation of the ranks'
+	tables sorted (stably) by primary -- zones interleave in index space, so unlike the other two modes the rank order
+	alone is not the global order (``gather_table`` sorts).
+
+	primary: this rank's shard of the primary catalogue (contiguous global rows, rank order); secondaries: list of this
+	rank's SLICES (contiguous global rows) of the secondary catalogues; ``error`` may be a scalar.
+	Hooks as in ``ShardedMatch`` (``_exchange_device``, ``_sync``, ``_build_plan``, ``step``, ``local_rows``,
+	``_local_columns``): the HIP pipeline here, the oracle in the CPU tests.
+	"""
+
+	ZONE_BINS = 1 << 16
+
+	def __init__(self, primary, secondaries, match_radius, prior_completeness, device, group=None,
+			prob_ratio_secondary=0.5, tuning=None, comm=None):
+		if isinstance(secondaries, dict):
+			secondaries = [secondaries]
+		self.comm = None  # (the set-up exchange is an all-to-all-v of rows through torch.distributed; nothing travels per step)
+		self.primary = primary
+		self.secondary_slices = secondaries
+		self.match_radius = float(match_radius)
+		self.prior_completeness = prior_completeness
+		self.prob_ratio_secondary = prob_ratio_secondary
+		self.device = device
+		self.group = group
+		self.tuning = tuning
+		self.rank, self.world = world_info(group)
+		self.plan = None
+		self.setup_seconds = None
+		self.setup()
+
+	# -- hooks ---------------------------------------------------------------------------
+	def _exchange_device(self):
+		return self.device
+
+	def _sync(self):
+		import torch
+		torch.cuda.synchronize(self.device)
+
+	# -- one-time exchange ---------------------------------------------------------------
+	def _global_sizes(self, n):
+		"""(sizes on every rank, in rank order) of a local row count"""
+		import torch
+		if self.world == 1:
+			return [int(n)]
+		t = torch.tensor([int(n)], dtype=torch.int64, device=self._exchange_device())
+		sizes = [torch.zeros_like(t) for _ in range(self.world)]
+		_dist().all_gather(sizes, t, group=self.group)
+		return [int(s.item()) for s in sizes]
+
+	def _zone_edges(self):
+		"""interior edges (world - 1 of them, ascending) of the declination zones: equal shares of the largest secondary catalogue"""
+		import torch
+		dist = _dist()
+		dev = self._exchange_device()
+		big = int(numpy.argmax(self.sec_global)) if self.sec_global else 0
+		dec = numpy.asarray(self.secondary_slices[big]['dec'], dtype=float) if self.secondary_slices else numpy.zeros(0)
+		dec = dec[numpy.isfinite(dec)]
+		lim = torch.tensor([dec.min() if len(dec) else numpy.inf, -(dec.max() if len(dec) else -numpy.inf)], dtype=torch.float64, device=dev)
+		if self.world > 1:
+			dist.all_reduce(lim, op=dist.ReduceOp.MIN, group=self.group)
+		lo, hi = float(lim[0].item()), -float(lim[1].item())
+		if not (hi > lo):
+			return numpy.full(self.world - 1, lo if numpy.isfinite(lo) else 0.0)
+		width = (hi - lo) / self.ZONE_BINS
+		hist = numpy.bincount(numpy.minimum(((dec - lo) / width).astype(numpy.int64), self.ZONE_BINS - 1), minlength=self.ZONE_BINS).astype(numpy.int64)
+		h = torch.as_tensor(hist).to(dev)
+		if self.world > 1:
+			dist.all_reduce(h, group=self.group)
+		cum = numpy.cumsum(h.cpu().numpy())
+		total = int(cum[-1])
+		edges = []
+		for z in range(1, self.world):
+			b = int(numpy.searchsorted(cum, (total * z) // self.world, side='left'))
+			edges.append(lo + (b + 1) * width)
+		return numpy.maximum.accumulate(numpy.asarray(edges, dtype=float))
+
+	def setup(self):
+		import torch
+		t0 = time.perf_counter()
+		dev = self._exchange_device()
+		world = self.world
+		self.primary_sizes = self._global_sizes(len(self.primary['ra']))
+		self.primary_offset = int(sum(self.primary_sizes[:self.rank]))
+		self.sec_global, self.sec_offset = [], []
+		for sl in self.secondary_slices:
+			sizes = self._global_sizes(len(sl['ra']))
+			self.sec_global.append(sum(sizes))
+			self.sec_offset.append(sum(sizes[:self.rank]))
+		from nway_amd import _hip
+		for n in [sum(self.primary_sizes)] + self.sec_global:
+			if n > _hip.CAPACITY_LIMIT:
+				raise _hip.NwayHipError('a catalogue of %d rows exceeds the int32 index range of the match table' % n)
+		self.edges = self._zone_edges()
+		margin = self.match_radius / 3600. * (1 + 1e-9) + 1e-12
+		self.moved_bytes = 0
+
+		def redistribute(table, offset, seams):
+			"""rows of ``table`` -> the ranks of their zones; returns host columns (ra, dec, error or scalar, global index)"""
+			ra = numpy.asarray(table['ra'], dtype=float)
+			dec = numpy.asarray(table['dec'], dtype=float)
+			scalar_error = numpy.ndim(table['error']) == 0
+			n = len(ra)
+			z_lo = numpy.searchsorted(self.edges, dec - (margin if seams else 0.0), side='right')
+			z_hi = numpy.searchsorted(self.edges, dec + (margin if seams else 0.0), side='right')
+			bad = ~numpy.isfinite(dec)
+			z_lo[bad] = z_hi[bad] = world - 1  # (a source without a declination matches nothing; a primary still has its row)
+			picks, counts = [], []
+			for z in range(world):
+				rows = numpy.flatnonzero((z_lo <= z) & (z <= z_hi))
+				picks.append(rows)
+				counts.append(len(rows))
+			rows = numpy.concatenate(picks) if picks else numpy.zeros(0, dtype=numpy.int64)
+			cols = [ra[rows], dec[rows]] + ([] if scalar_error else [numpy.asarray(table['error'], dtype=float)[rows]]) + [(rows + offset).astype(float)]
+			packed = torch.as_tensor(numpy.ascontiguousarray(numpy.stack(cols, axis=1))).to(dev)
+			self.moved_bytes += int(packed.numel()) * 8
+			got = exchange_rows(packed, counts, self.group).cpu().numpy()
+			out = dict(name=table['name'], ra=numpy.ascontiguousarray(got[:, 0]), dec=numpy.ascontiguousarray(got[:, 1]), area=table['area'],
+				error=(float(table['error']) if scalar_error else numpy.ascontiguousarray(got[:, 2])), mags=[], maghists=[], magnames=[])
+			return out, got[:, -1].astype(numpy.int64)
+		self.zone_primary, self.primary_gidx = redistribute(self.primary, self.primary_offset, False)
+		self.zone_secondaries, self.sec_gidx = [], []
+		for sl, off in zip(self.secondary_slices, self.sec_offset):
+			t, g = redistribute(sl, off, True)
+			self.zone_secondaries.append(t)
+			self.sec_gidx.append(g)
+		self._sync()
+		self.setup_seconds = time.perf_counter() - t0
+		self._decide()
+		self._build_plan()
+
+	def _decide(self):
+		"""densities and cell scheme of the WHOLE catalogues (every rank must use the same)"""
+		import torch
+		import nway_amd
+		from nway_amd import _hip
+		log = nway_amd.NullOutputLogger()
+		names = [self.primary['name']] + [s['name'] for s in self.secondary_slices]
+		self.global_sizes = [int(sum(self.primary_sizes))] + self.sec_global
+		areas = [self.primary['area']] + [s['area'] for s in self.secondary_slices]
+		self.dens, self.dens_plus = nway_amd._densities_from_sizes(names, self.global_sizes, areas, log)
+		err = self.match_radius / 60. / 60
+		local = [(numpy.asarray(self.primary['ra'], dtype=float), numpy.asarray(self.primary['dec'], dtype=float))]
+		local += [(numpy.asarray(s['ra'], dtype=float), numpy.asarray(s['dec'], dtype=float)) for s in self.secondary_slices]
+		scheme = nway_amd.choose_scheme([t for t in local if len(t[0]) > 0], err) if any(len(t[0]) for t in local) else _hip.SCHEME_FLAT
+		if self.world > 1:
+			s = torch.tensor([scheme], dtype=torch.int64, device=self._exchange_device())
+			_dist().all_reduce(s, op=_dist().ReduceOp.MAX, group=self.group)  # the all-sky scheme wins
+			scheme = int(s.item())
+		self.scheme = scheme
+
+	def _build_plan(self):
+		import nway_amd
+		from nway_amd import _hip
+		tables = [self.zone_primary] + self.zone_secondaries
+		k = len(tables)
+		err = self.match_radius / 60. / 60
+		comp = nway_amd._completeness_vector(self.prior_completeness, k)
+		self.params = _hip.make_params(k, self.scheme, self.match_radius, err, self.dens, self.dens_plus,
+			nway_amd._prior_table(self.dens, self.dens_plus, comp), prob_ratio_secondary=self.prob_ratio_secondary, tuning=self.tuning)
+		self.empty = len(self.zone_primary['ra']) == 0  # (a zone without primaries has no rows)
+		self.cats = [_hip.DeviceCatalogue(t['ra'], t['dec'], numpy.asarray(t['error'], dtype=float), self.device) for t in tables]
+		if self.empty:
+			self.plan, self.status = None, numpy.zeros(_hip.STATUS_WORDS, dtype=numpy.int64)
+			return
+		sizes = [c.n for c in self.cats]
+		# (capacities from the densities of the whole job: the zone's share of the sky is not known to the estimate)
+		areas = [t['area'] * max(n, 1) / max(g, 1) for t, n, g in zip(tables, sizes, self.global_sizes)]
+		cap_pairs, cap_rows = nway_amd._estimate_capacities(sizes, areas, self.match_radius, self.scheme, True)
+		self.plan, self.status = _hip.run_plan(sizes, self.params, self.cats, cap_pairs, cap_rows, self.device, lean=True)
+
+	# -- per step ------------------------------------------------------------------------
+	def step(self, cats=None):
+		"""one pass of the hot path over this rank's zone (no collective)"""
+		if not self.empty:
+			self.plan.enqueue(self.cats if cats is None else cats)
+
+	def read_status(self):
+		return self.status if self.plan is None else self.plan.read_status()
+
+	def local_rows(self):
+		from nway_amd import _hip
+		return int(self.read_status()[_hip.ST_ROWS])
+
+	def total_rows(self):
+		import torch
+		n = self.local_rows()
+		if self.world == 1:
+			return n
+		t = torch.tensor([n], dtype=torch.int64, device=self._exchange_device())
+		_dist().all_reduce(t, group=self.group)
+		return int(t.item())
+
+	def pass_bytes(self, rows):
+		"""algorithmic bytes of this rank's pass: the primaries and secondaries of its zone read once + its rows"""
+		tables = [self.zone_primary] + self.zone_secondaries
+		k = len(tables)
+		b = sum(len(t['ra']) * (16.0 + (8.0 if numpy.ndim(t['error']) > 0 else 0.0)) for t in tables)
+		return b + (4 * k + 8 * (k * (k - 1) // 2) + 8 + 1 + 8 * 5 + 1) * rows
+
+	def _local_columns(self):
+		"""the rows of this rank's zone as host columns, LOCAL indices"""
+		from nway_amd import _hip
+		names = [self.primary['name']] + [s['name'] for s in self.secondary_slices]
+		if self.plan is None:
+			t = dict((nme, numpy.zeros(0, dtype=numpy.int64)) for nme in names + ['ncat', 'match_flag'])
+			for i, j in _hip.pair_columns(len(names)):
+				t['Separation_%s_%s' % (names[i], names[j])] = numpy.zeros(0)
+			for dst in ('Separation_max', 'dist_bayesfactor_uncorrected', 'dist_bayesfactor', 'dist_post', 'p_single', 'prob_has_match', 'prob_this_match'):
+				t[dst] = numpy.zeros(0)
+			return t
+		m = int(self.plan.read_status()[_hip.ST_ROWS])
+		t = {}
+		for c, nme in enumerate(names):
+			t[nme] = _hip.to_host(self.plan.cols['idx'][c][:m]).astype(numpy.int64)
+		for p, (i, j) in enumerate(_hip.pair_columns(len(names))):
+			t['Separation_%s_%s' % (names[i], names[j])] = _hip.to_host(self.plan.cols['sep'][p][:m])
+		for src, dst in (('sep_max', 'Separation_max'), ('log_bf', 'dist_bayesfactor_uncorrected'), ('log_bf_corrected', 'dist_bayesfactor'),
+				('dist_post', 'dist_post'), ('p_single', 'p_single'), ('p_any', 'prob_has_match'), ('p_i', 'prob_this_match')):
+			t[dst] = _hip.to_host(self.plan.cols[src][:m])
+		t['ncat'] = _hip.to_host(self.plan.cols['ncat'][:m]).astype(numpy.int64)
+		t['match_flag'] = _hip.to_host(self.plan.cols['match_flag'][:m]).astype(numpy.int64)
+		return t
+
+	def local_table(self):
+		"""this rank's rows as host columns, GLOBAL indices throughout (ascending in the primary)"""
+		t = dict(self._local_columns())
+		names = [self.primary['name']] + [s['name'] for s in self.secondary_slices]
+		for nme, g in zip(names, [self.primary_gidx] + self.sec_gidx):
+			col = numpy.asarray(t[nme], dtype=numpy.int64)
+			t[nme] = numpy.where(col >= 0, g[numpy.maximum(col, 0)], -1) if len(g) else col
+		return t
+
+	def gather_table(self, dst=0):
+		"""global table on rank ``dst``: the ranks' tables concatenated and sorted (stably) by primary; None elsewhere"""
+		dist = _dist()
+		local = self.local_table()
+		gathered = [local]
+		if self.world > 1:
+			gathered = [None] * self.world if self.rank == dst else None
+			dist.gather_object(local, gathered, dst=dst, group=self.group)
+			if self.rank != dst:
+				return None
+		out = {}
+		fullest = max(gathered, key=lambda g: len(g[self.primary['name']]))  # (a zone without primaries may know fewer columns)
+		for key in fullest:
+			if not key.startswith('_'):
+				out[key] = numpy.concatenate([numpy.asarray(g[key]) for g in gathered if key in g and len(g[self.primary['name']]) > 0] or [numpy.asarray(fullest[key])[:0]])
+		order = numpy.argsort(out[self.primary['name']], kind='stable')
+		return dict((key, col[order]) for key, col in out.items())

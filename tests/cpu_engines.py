@@ -126,3 +126,37 @@ class OracleSecondarySplitMatch(distributed.SecondarySplitMatch):
 
 	def local_table(self):
 		return dict(self.table)
+
+
+class OracleZoneShardedMatch(distributed.ZoneShardedMatch):
+	"""both sides sharded by declination zones (one all-to-all-v of rows at set-up, through gloo); the match of a zone is the
+	numpy oracle with the densities and the cell scheme of the whole catalogues"""
+
+	def _exchange_device(self):
+		return torch.device('cpu')
+
+	def _sync(self):
+		pass
+
+	def _build_plan(self):
+		self.empty = len(self.zone_primary['ra']) == 0
+		self.table = None
+
+	def step(self):
+		import nway_oracle as orc
+		names = [self.primary['name']] + [s['name'] for s in self.secondary_slices]
+		if self.empty:
+			t = dict((n, np.zeros(0, dtype=np.int64)) for n in names + ['ncat', 'match_flag'])
+			self.table = t
+			return t
+		tables = [self.zone_primary] + self.zone_secondaries
+		tables = [dict(t, error=(np.broadcast_to(np.asarray(t['error'], dtype=float), np.shape(t['ra'])))) for t in tables]
+		self.table = orc.nway_match(tables, self.match_radius, self.prior_completeness, prob_ratio_secondary=self.prob_ratio_secondary,
+			densities=(self.dens, self.dens_plus), scheme=self.scheme)
+		return self.table
+
+	def local_rows(self):
+		return len(self.table['ncat'])
+
+	def _local_columns(self):
+		return dict(self.table)

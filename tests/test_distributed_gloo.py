@@ -134,3 +134,62 @@ def test_secondary_split_equals_unsharded(tmp_path, k):
 		if key.startswith('_'):
 			continue
 		np.testing.assert_array_equal(got[key], want[key], err_msg=key)
+
+
+# ---- zone mode (both sides sharded by declination zones; one all-to-all-v of rows at set-up, no collective per step) ----
+
+def zone_worker(rank, world, port, outfile, k):
+	os.environ['MASTER_ADDR'] = '127.0.0.1'
+	os.environ['MASTER_PORT'] = str(port)
+	dist.init_process_group('gloo', rank=rank, world_size=world)
+	try:
+		from nway_amd import distributed
+		# the all-to-all-v of rows by itself: rank r sends r + d + 1 rows to rank d, tagged with (source, destination, number)
+		counts = [rank + d + 1 for d in range(world)]
+		rows = torch.tensor([[rank, d, i] for d in range(world) for i in range(counts[d])], dtype=torch.float64)
+		got = distributed.exchange_rows(rows, counts).numpy()
+		want = np.array([[s, rank, i] for s in range(world) for i in range(s + rank + 1)], dtype=float)
+		np.testing.assert_array_equal(got, want)
+
+		A, B, C = make_catalogues()
+		pb = [0, 150, len(A['ra'])] if world == 2 else distributed.shard_bounds(len(A['ra']), world)   # uneven input shards of every catalogue
+		bb = [0, 3500, len(B['ra'])] if world == 2 else distributed.shard_bounds(len(B['ra']), world)
+		cb = [0, 1200, len(C['ra'])] if world == 2 else distributed.shard_bounds(len(C['ra']), world)
+		def rows_of(t, lo, hi):
+			return dict(t, ra=t['ra'][lo:hi], dec=t['dec'][lo:hi], error=t['error'][lo:hi])
+		secs = [rows_of(B, bb[rank], bb[rank + 1]), rows_of(C, cb[rank], cb[rank + 1])][:k - 1]
+		from cpu_engines import OracleZoneShardedMatch
+		zm = OracleZoneShardedMatch(rows_of(A, pb[rank], pb[rank + 1]), secs, 20., 0.85, device=torch.device('cpu'))
+		assert zm.primary_offset == pb[rank] and zm.sec_global == [len(B['ra']), len(C['ra'])][:k - 1]
+		assert len(zm.edges) == world - 1 and (np.diff(zm.edges) >= 0).all()
+		# every primary of the job has exactly one owner; the zones' secondaries overlap in the seams only
+		own = torch.tensor([len(zm.zone_primary['ra']), len(zm.zone_secondaries[0]['ra'])], dtype=torch.int64)
+		dist.all_reduce(own)
+		assert int(own[0]) == len(A['ra']) and len(B['ra']) <= int(own[1]) <= 1.2 * len(B['ra'])
+		assert (np.diff(zm.primary_gidx) > 0).all() and (np.diff(zm.sec_gidx[0]) > 0).all()  # (ascending global indices: the rows' order)
+		zm.step()
+		total = zm.total_rows()
+		table = zm.gather_table(dst=0)
+		if rank == 0:
+			np.savez(outfile, total=total, zone_rows=zm.local_rows(), **table)
+	finally:
+		dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world,k', [(2, 2), (2, 3), (3, 3)])
+def test_zone_sharded_equals_unsharded(tmp_path, world, k):
+	"""primaries AND secondaries redistributed by declination zones (edges from the summed histogram of the largest secondary
+	catalogue; the secondaries inside the seams go to both neighbours); the ranks' tables, concatenated and sorted by primary,
+	are the unsharded table -- global indices, row order inside the groups, every value"""
+	import nway_oracle as orc
+	outfile = str(tmp_path / 'zones.npz')
+	mp.spawn(zone_worker, args=(world, free_port(), outfile, k), nprocs=world, join=True)
+	got = np.load(outfile)
+	A, B, C = make_catalogues()
+	want = orc.nway_match([A, B, C][:k], 20., 0.85)
+	assert int(got['total']) == len(want['ncat']) > 400
+	assert 0 < int(got['zone_rows']) < int(got['total'])
+	for key in want:
+		if key.startswith('_'):
+			continue
+		np.testing.assert_array_equal(got[key], want[key], err_msg=key)

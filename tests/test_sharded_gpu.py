@@ -105,6 +105,59 @@ def test_primary_shards_on_device(tmp_path, k, flat, cut):
 		np.testing.assert_allclose(got[c], o[c], rtol=RTOL, atol=ATOL, err_msg=c)
 
 
+def zone_worker(rank, world, port, outfile, k, flat):
+	os.environ['MASTER_ADDR'] = '127.0.0.1'
+	os.environ['MASTER_PORT'] = str(port)
+	os.environ['HSA_ENABLE_IPC_MODE_LEGACY'] = '0'
+	dist.init_process_group('gloo', rank=rank, world_size=world)
+	try:
+		sys.path.insert(0, ROOT)
+		from nway_amd import distributed
+		tabs = catalogues(k, flat)
+		dev = torch.device('cuda', 0)
+		torch.cuda.set_device(dev)
+		def rows(t, lo, hi):
+			return dict(t, ra=t['ra'][lo:hi], dec=t['dec'][lo:hi], error=t['error'][lo:hi])
+		parts = []
+		for c, t in enumerate(tabs):
+			n = len(t['ra'])
+			cut = [0, int((0.7, 0.41, 0.55)[c] * n), n]  # uneven input shards of every catalogue
+			parts.append(rows(t, cut[rank], cut[rank + 1]))
+		zm = distributed.ZoneShardedMatch(parts[0], parts[1:], 10., 0.9, device=dev)
+		# the zone of a rank: about half of every catalogue (the edges are quantiles of the largest secondary catalogue)
+		assert 0.3 * len(tabs[1]['ra']) < zm.cats[1].n < 0.7 * len(tabs[1]['ra'])
+		for _ in range(3):  # (repeated steps recycle the scratch copies)
+			zm.step()
+		total = zm.total_rows()
+		table = zm.gather_table(dst=0)
+		if rank == 0:
+			np.savez(outfile, total=total, zone_rows=zm.local_rows(), **table)
+	finally:
+		dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('k,flat', [(2, False), (3, False), (2, True), (3, True)])
+def test_declination_zones_on_device(tmp_path, k, flat):
+	"""both sides sharded by declination zones (ZoneShardedMatch), two gloo ranks on the one GPU through the HIP pipeline: the
+	ranks' tables, concatenated and sorted by primary, equal the single-GPU table bit for bit (and the C oracle's)"""
+	import nway_amd as nw
+	import nway_oracle_c as orc_c
+	outfile = str(tmp_path / 'zones.npz')
+	mp.spawn(zone_worker, args=(2, free_port(), outfile, k, flat), nprocs=2, join=True)
+	got = np.load(outfile)
+	tabs = catalogues(k, flat)
+	want = nw.nway_match(tabs, 10., 0.9, logger=nw.NullOutputLogger())
+	assert int(got['total']) == len(want) > len(tabs[0]['ra'])
+	assert 0.3 * len(want) < int(got['zone_rows']) < 0.7 * len(want)
+	for key in want.columns:
+		np.testing.assert_array_equal(got[key], want[key].values, err_msg=key)
+	o = orc_c.nway_match(tabs, 10., 0.9)
+	for n in [t['name'] for t in tabs] + ['ncat', 'match_flag']:
+		np.testing.assert_array_equal(got[n], o[n])
+	for c in ('Separation_max', 'dist_bayesfactor', 'dist_post', 'p_single', 'prob_has_match', 'prob_this_match'):
+		np.testing.assert_allclose(got[c], o[c], rtol=RTOL, atol=ATOL, err_msg=c)
+
+
 @pytest.mark.parametrize('scaling', ['weak', 'strong'])
 def test_bench_under_torchrun_two_ranks(tmp_path, scaling):
 	"""bench.py as the driver launches it for N > 1 (one process per rank, torch.distributed.run), here
@@ -215,25 +268,32 @@ def test_bench_one_rank_through_rccl(scaling, comm):
 	assert out['config']['parallelism'].startswith('secondary-stream' if scaling == 'strong' else 'primary-row')
 
 
-EXTRA_JOBS = ['c3s_split', 'c4s_rows', 'c5_rows', 'c5_split']
+EXTRA_JOBS = ['c3s_split', 'c4s_rows', 'c5_rows', 'c5_split', 'c3s_zones', 'c4s_zones', 'c5_zones']
 
 
 def check_extra_configs(out, world, comms, scale):
 	"""bench.py's extra_configs block: the fixed-size jobs BASELINE names for several GPUs, one record per job and carrier"""
 	recs = out['extra_configs']
-	assert [(r['job'], r['exchanges'].split(' ')[0]) for r in recs] == [(j, c) for j in EXTRA_JOBS for c in comms], [(r['job'], r['exchanges']) for r in recs]
+	assert [(r['job'], r['exchanges'].split(' ')[0]) for r in recs] == [(j, c) for j in EXTRA_JOBS for c in (comms if not j.endswith('zones') else comms[:1])], [
+		(r['job'], r['exchanges']) for r in recs]
 	for r in recs:
 		assert 'error' not in r, r
 		assert r['n_gpus'] == world and r['ranks_seen'] == world and r['flags'] == 0 and r['scaling'] == 'strong'
 		assert r['ms_per_step'] > 0 and r['value'] > 0 and 0 < r['pass_frac'] < 1 and 0 < r['rank0_pass_frac'] < 1
 		n0 = r['sizes'][0]
-		assert n0 == max(int({'c3s_split': 1e5, 'c4s_rows': 1e5, 'c5_rows': 5e5, 'c5_split': 5e5}[r['job']] * scale), 8 * world)
+		assert n0 == max(int({'c3s': 1e5, 'c4s': 1e5, 'c5': 5e5}[r['job'].split('_')[0]] * scale), 8 * world)
 		# rows of the WHOLE job: every primary once + its counterparts (80 %; the 3-way job: (1 + 0.8)(1 + 0.6) rows per primary)
-		per = 2.88 if r['job'] == 'c4s_rows' else 1.8
+		per = 2.88 if r['job'].startswith('c4s') else 1.8
 		assert 0.9 * per * n0 < r['rows'] < 1.1 * per * n0 + 50, r
 		if r['job'].endswith('split'):
 			assert r['mode'].startswith('secondary-stream') and 0 < r['exchange_block_records_used'] <= r['exchange_block_records']
 			assert r['exchange_block_records'] <= 2 * r['exchange_block_records_used'] + 64   # (sized by the settling step)
+		elif r['job'].endswith('zones'):
+			# every rank streams about 1 / world of every secondary catalogue (+ the seams), and sent its input shard once
+			assert r['mode'].startswith('declination zones')
+			for zone_n, n in zip(r['rank0_zone_sizes'][1:], r['sizes'][1:]):
+				assert 0.5 * n / world <= zone_n <= 1.5 * n / world + 64, r
+			assert r['setup_exchange_bytes'] >= 24 * sum(r['sizes'][1:]) // world
 		else:
 			assert r['mode'].startswith('primary-row') and r['setup_exchange_bytes'] >= 16 * sum(r['sizes'][1:])
 
