@@ -151,6 +151,12 @@ class OracleZoneShardedMatch(distributed.ZoneShardedMatch):
 			return t
 		tables = [self.zone_primary] + self.zone_secondaries
 		tables = [dict(t, error=(np.broadcast_to(np.asarray(t['error'], dtype=float), np.shape(t['ra'])))) for t in tables]
+		for c in range(1, len(tables)):
+			if len(tables[c]['ra']) == 0:
+				# (the numpy oracle, like the reference, cannot index an empty catalogue -- the HIP path can, tests/test_hip_parity.py:
+				# one source on the far side of the sky stands in; densities and scheme are the whole job's, handed in below)
+				p0 = tables[0]
+				tables[c] = dict(tables[c], ra=np.array([(np.nanmean(p0['ra']) + 180.0) % 360.0]), dec=np.array([-np.nanmean(p0['dec'])]), error=np.array([1.0]))
 		self.table = orc.nway_match(tables, self.match_radius, self.prior_completeness, prob_ratio_secondary=self.prob_ratio_secondary,
 			densities=(self.dens, self.dens_plus), scheme=self.scheme)
 		return self.table

@@ -193,3 +193,66 @@ def test_zone_sharded_equals_unsharded(tmp_path, world, k):
 		if key.startswith('_'):
 			continue
 		np.testing.assert_array_equal(got[key], want[key], err_msg=key)
+
+
+def zone_edge_worker(rank, world, port, outfile, case):
+	os.environ['MASTER_ADDR'] = '127.0.0.1'
+	os.environ['MASTER_PORT'] = str(port)
+	dist.init_process_group('gloo', rank=rank, world_size=world)
+	try:
+		from nway_amd import distributed
+		from cpu_engines import OracleZoneShardedMatch
+		A, B, C = zone_edge_catalogues(case)
+		def rows_of(t, b):
+			return dict(t, ra=t['ra'][b[rank]:b[rank + 1]], dec=t['dec'][b[rank]:b[rank + 1]], error=t['error'][b[rank]:b[rank + 1]])
+		pb, bb, cb = [distributed.shard_bounds(len(t['ra']), world) for t in (A, B, C)]
+		if case == 'lopsided':
+			pb = [0, 0, len(A['ra']) // 3, len(A['ra'])]  # (a rank that brings no primaries at all)
+		zm = OracleZoneShardedMatch(rows_of(A, pb), [rows_of(B, bb), rows_of(C, cb)], 20., 0.85, device=torch.device('cpu'))
+		zm.step()
+		total = zm.total_rows()
+		sizes = torch.tensor([len(zm.zone_primary['ra']), len(zm.zone_secondaries[0]['ra']), len(zm.zone_secondaries[1]['ra'])], dtype=torch.int64)
+		allsizes = [torch.zeros_like(sizes) for _ in range(world)]
+		dist.all_gather(allsizes, sizes)
+		table = zm.gather_table(dst=0)
+		if rank == 0:
+			np.savez(outfile, total=total, zone_sizes=torch.stack(allsizes).numpy(), **table)
+	finally:
+		dist.destroy_process_group()
+
+
+def zone_edge_catalogues(case):
+	rng = np.random.RandomState(5)
+	def patch(n, name, err, dec_lo, dec_hi):
+		return cat(name, rng.uniform(30.0, 30.3, size=n), rng.uniform(dec_lo, dec_hi, size=n), rng.uniform(0.5 * err, err, size=n), 0.09)
+	if case == 'one_declination':
+		# every source of the largest catalogue on ONE declination: the edges collapse, one rank owns everything
+		A, B, C = patch(120, 'A', 3., 0.1, 0.1), patch(2000, 'B', 1., 0.1, 0.1), patch(900, 'C', 2., 0.1 - 0.002, 0.1 + 0.002)
+	else:
+		# the third catalogue lies in the southern third only: two zones hold none of it; a primary with a NaN declination keeps its row
+		A, B, C = patch(300, 'A', 3., -0.15, 0.15), patch(3000, 'B', 1., -0.15, 0.15), patch(700, 'C', 2., -0.15, -0.06)
+		A['dec'][7] = np.nan
+		B['dec'][11] = np.nan
+	return A, B, C
+
+
+@pytest.mark.parametrize('case', ['lopsided', 'one_declination'])
+def test_zone_sharded_edge_cases(tmp_path, case):
+	"""zones that hold nothing of a catalogue, a rank without input primaries, NaN declinations, collapsed zone edges (world 3)"""
+	import nway_oracle as orc
+	outfile = str(tmp_path / 'zones_edge.npz')
+	mp.spawn(zone_edge_worker, args=(3, free_port(), outfile, case), nprocs=3, join=True)
+	got = np.load(outfile)
+	A, B, C = zone_edge_catalogues(case)
+	want = orc.nway_match([A, B, C], 20., 0.85)
+	zs = got['zone_sizes']
+	assert zs[:, 0].sum() == len(A['ra'])
+	if case == 'lopsided':
+		assert (zs[:, 2] == 0).sum() >= 1 and (zs[:, 0] > 0).all()  # (a zone with primaries and nothing of catalogue C)
+	else:
+		assert (zs[:, 0] > 0).sum() == 1  # (one rank owns every primary)
+	assert int(got['total']) == len(want['ncat'])
+	for key in want:
+		if key.startswith('_'):
+			continue
+		np.testing.assert_array_equal(got[key], want[key], err_msg=key)
