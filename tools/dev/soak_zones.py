@@ -1,0 +1,109 @@
+"""development aid: the declination-zone sharding (nway_amd.distributed.ZoneShardedMatch) against the unsharded run on the GPU, over a
+seed range of the randomised configurations of tests/test_hip_fuzz.py (2 to 5 catalogues, flat and all-sky, sparse and dense):
+the zones are cut as the engine cuts them (quantiles of the largest secondary catalogue, seams of one match radius), every zone's
+pass runs through the engine's own plan / table code with the densities and the cell scheme of the whole job, and the zones' tables --
+global indices, concatenated, sorted by primary -- must equal the table of the whole job in EVERY column, bit for bit.
+    python tools/dev/soak_zones.py 0 60        (on the GPU box)
+"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+import numpy as np
+import torch
+import test_hip_fuzz as fz
+import nway_amd as nw
+from nway_amd import _hip, distributed
+
+dev = torch.device('cuda', 0)
+
+
+class OneZone(distributed.ZoneShardedMatch):
+	"""the engine's plan and table code on a zone cut here (one process: no exchange)"""
+
+	def __init__(self, zone_tables, gidx, whole, radius, completeness, scheme):
+		self.comm = None
+		self.primary = zone_tables[0]
+		self.secondary_slices = zone_tables[1:]
+		self.zone_primary, self.zone_secondaries = zone_tables[0], zone_tables[1:]
+		self.primary_gidx, self.sec_gidx = gidx[0], gidx[1:]
+		self.match_radius = float(radius)
+		self.prior_completeness = completeness
+		self.prob_ratio_secondary = 0.5
+		self.device = dev
+		self.group = None
+		self.tuning = None
+		self.rank, self.world = 0, 1
+		self.plan = None
+		self.primary_sizes = [len(whole[0]['ra'])]
+		self.sec_global = [len(t['ra']) for t in whole[1:]]
+		self._decide()
+		self.scheme = scheme  # (of the whole job)
+		self._build_plan()
+
+
+def whole_table(tables, radius, completeness):
+	n = [len(t['ra']) for t in tables]
+	ident = [np.arange(x) for x in n]
+	err = radius / 3600.
+	scheme = nw.choose_scheme([(t['ra'], t['dec']) for t in tables], err)
+	z = OneZone(tables, ident, tables, radius, completeness, scheme)
+	z.step()
+	t = z.gather_table()
+	if z.plan is not None:
+		z.plan.close()
+	return t, scheme
+
+
+lo, hi = int(sys.argv[1]), int(sys.argv[2])
+bad, t0, rows = [], time.time(), 0
+for seed in range(lo, hi):
+	rng = np.random.default_rng(7000 + seed)
+	k = int(rng.integers(2, 6))
+	tabs, radius = (fz.flat_case if seed % 2 == 0 else fz.sphere_case)(rng, k)
+	if seed % 2 == 1 and k > 4:
+		tabs = tabs[:4]
+	comp = float(rng.choice([1.0, 0.9, 0.5]))
+	try:
+		want, scheme = whole_table(tabs, radius, comp)
+		world = int(rng.choice([2, 3, 5]))
+		big = 1 + int(np.argmax([len(t['ra']) for t in tabs[1:]]))
+		dec = np.asarray(tabs[big]['dec'], dtype=float)
+		edges = np.quantile(dec[np.isfinite(dec)], [z / world for z in range(1, world)]) if np.isfinite(dec).any() else np.zeros(world - 1)
+		margin = radius / 3600. * (1 + 1e-9) + 1e-12
+		parts = []
+		for z in range(world):
+			zt, gidx = [], []
+			for c, t in enumerate(tabs):
+				m = margin if c > 0 else 0.0
+				d = np.asarray(t['dec'], dtype=float)
+				z_lo = np.searchsorted(edges, d - m, side='right')
+				z_hi = np.searchsorted(edges, d + m, side='right')
+				nan = ~np.isfinite(d)
+				z_lo[nan] = z_hi[nan] = world - 1
+				pick = np.flatnonzero((z_lo <= z) & (z <= z_hi))
+				zt.append(dict(t, ra=np.ascontiguousarray(np.asarray(t['ra'], dtype=float)[pick]), dec=np.ascontiguousarray(d[pick]),
+					error=(t['error'] if np.ndim(t['error']) == 0 else np.ascontiguousarray(np.asarray(t['error'], dtype=float)[pick]))))
+				gidx.append(pick)
+			eng = OneZone(zt, gidx, tabs, radius, comp, scheme)
+			eng.step()
+			parts.append(eng.local_table())
+			if eng.plan is not None:
+				eng.plan.close()
+		pname = tabs[0]['name']
+		fullest = max(parts, key=lambda g: len(g[pname]))
+		got = dict((key, np.concatenate([np.asarray(g[key]) for g in parts if len(g[pname]) > 0] or [np.asarray(fullest[key])[:0]])) for key in fullest)
+		order = np.argsort(got[pname], kind='stable')
+		assert len(got[pname]) == len(want[pname]), (len(got[pname]), len(want[pname]))
+		for key in want:
+			a, b = got[key][order], np.asarray(want[key])
+			same = (a == b) | ((a != a) & (b != b))
+			assert same.all(), '%s: %d rows differ' % (key, (~same).sum())
+		rows += len(want[pname])
+	except Exception as e:
+		bad.append(seed)
+		print('seed %d (k %d, %s, world %s) FAILED: %s' % (seed, len(tabs), 'flat' if seed % 2 == 0 else 'sphere', locals().get('world'), str(e).strip().splitlines()[0][:200]))
+print('zone soak seeds %d..%d: %d rows compared bit for bit, %d failures %s, %.0f s' % (lo, hi - 1, rows, len(bad), bad, time.time() - t0))
