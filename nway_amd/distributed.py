@@ -770,10 +770,12 @@ class ZoneShardedMatch(object):
 			cols = [ra[rows], dec[rows]] + ([] if scalar_error else [numpy.asarray(table['error'], dtype=float)[rows]]) + [(rows + offset).astype(float)]
 			packed = torch.as_tensor(numpy.ascontiguousarray(numpy.stack(cols, axis=1))).to(dev)
 			self.moved_bytes += int(packed.numel()) * 8
-			got = exchange_rows(packed, counts, self.group).cpu().numpy()
-			out = dict(name=table['name'], ra=numpy.ascontiguousarray(got[:, 0]), dec=numpy.ascontiguousarray(got[:, 1]), area=table['area'],
-				error=(float(table['error']) if scalar_error else numpy.ascontiguousarray(got[:, 2])), mags=[], maghists=[], magnames=[])
-			return out, got[:, -1].astype(numpy.int64)
+			got = exchange_rows(packed, counts, self.group)
+			# (the columns stay where they arrived -- on the GPU in the product, tensors the plan takes as they are; the global
+			# indices are host-side bookkeeping)
+			out = dict(name=table['name'], ra=got[:, 0].contiguous(), dec=got[:, 1].contiguous(), area=table['area'],
+				error=(float(table['error']) if scalar_error else got[:, 2].contiguous()), mags=[], maghists=[], magnames=[])
+			return out, got[:, -1].cpu().numpy().astype(numpy.int64)
 		self.zone_primary, self.primary_gidx = redistribute(self.primary, self.primary_offset, False)
 		self.zone_secondaries, self.sec_gidx = [], []
 		for sl, off in zip(self.secondary_slices, self.sec_offset):
@@ -815,7 +817,7 @@ class ZoneShardedMatch(object):
 		self.params = _hip.make_params(k, self.scheme, self.match_radius, err, self.dens, self.dens_plus,
 			nway_amd._prior_table(self.dens, self.dens_plus, comp), prob_ratio_secondary=self.prob_ratio_secondary, tuning=self.tuning)
 		self.empty = len(self.zone_primary['ra']) == 0  # (a zone without primaries has no rows)
-		self.cats = [_hip.DeviceCatalogue(t['ra'], t['dec'], numpy.asarray(t['error'], dtype=float), self.device) for t in tables]
+		self.cats = [_hip.DeviceCatalogue(t['ra'], t['dec'], t['error'], self.device) for t in tables]  # (tensors as they arrived; a scalar error stays one)
 		if self.empty:
 			self.plan, self.status = None, numpy.zeros(_hip.STATUS_WORDS, dtype=numpy.int64)
 			return
@@ -851,7 +853,7 @@ class ZoneShardedMatch(object):
 		"""algorithmic bytes of this rank's pass: the primaries and secondaries of its zone read once + its rows"""
 		tables = [self.zone_primary] + self.zone_secondaries
 		k = len(tables)
-		b = sum(len(t['ra']) * (16.0 + (8.0 if numpy.ndim(t['error']) > 0 else 0.0)) for t in tables)
+		b = sum(len(t['ra']) * (16.0 + (8.0 if hasattr(t['error'], 'shape') and len(t['error'].shape) > 0 else 0.0)) for t in tables)
 		return b + (4 * k + 8 * (k * (k - 1) // 2) + 8 + 1 + 8 * 5 + 1) * rows
 
 	def _local_columns(self):

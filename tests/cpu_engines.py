@@ -150,7 +150,7 @@ class OracleZoneShardedMatch(distributed.ZoneShardedMatch):
 			self.table = t
 			return t
 		tables = [self.zone_primary] + self.zone_secondaries
-		tables = [dict(t, error=(np.broadcast_to(np.asarray(t['error'], dtype=float), np.shape(t['ra'])))) for t in tables]
+		tables = [dict(t, ra=np.asarray(t['ra']), dec=np.asarray(t['dec']), error=(np.broadcast_to(np.asarray(t['error'], dtype=float), np.shape(t['ra'])))) for t in tables]
 		for c in range(1, len(tables)):
 			if len(tables[c]['ra']) == 0:
 				# (the numpy oracle, like the reference, cannot index an empty catalogue -- the HIP path can, tests/test_hip_parity.py:
