@@ -16,7 +16,7 @@ import numpy as np
 import nway_amd as nw
 import nway_oracle_c as orc_c
 from nway_amd import _hip
-from goldenutil import cat
+from goldenutil import cat, soak_compare
 from test_full_size import hip_table, compare
 
 lo, hi = int(sys.argv[1]), int(sys.argv[2])
@@ -63,7 +63,7 @@ for seed in range(lo, hi):
 		for key in q:
 			if not key.startswith('_'):
 				np.testing.assert_array_equal(q[key], lane[key], err_msg=key)
-		compare(q, orc_c.nway_match(tabs, radius, comp, correction='cli' if corr else 'api'), names)
+		soak_compare(q, orc_c.nway_match(tabs, radius, comp, correction='cli' if corr else 'api'), names)  # (goldenutil: near-zero log Bayes factors by their absolute error)
 		rows += len(q['ncat'])
 		tails[q['_desc']['tail']] = tails.get(q['_desc']['tail'], 0) + 1
 		groups = np.bincount(q['P'].astype(np.int64), minlength=n0)

@@ -18,10 +18,10 @@ import nway_amd as nw
 import nway_oracle_c as orc_c
 from goldenutil import cat
 from test_full_size import hip_table, compare
-from goldenutil import RTOL, ATOL_LOG
+from goldenutil import soak_compare
 
 lo, hi = int(sys.argv[1]), int(sys.argv[2])
-bad, t0, rows, tails = [], time.time(), 0, {}
+bad, t0, rows, tails, flips = [], time.time(), 0, {}, 0
 for seed in range(lo, hi):
 	rng = np.random.default_rng(12000 + seed)
 	n0 = int(10 ** rng.uniform(3, 5.3))
@@ -74,11 +74,8 @@ for seed in range(lo, hi):
 				np.testing.assert_array_equal(q[key], g[key], err_msg=key)
 		otabs = [tabs[0], dict(sec, error=np.broadcast_to(np.asarray(sec['error'], dtype=float), (ns,)).copy())]
 		o = orc_c.nway_match(otabs, radius, comp, f32_roundtrip=f32)
-		# (a log Bayes factor that happens to come out near zero carries the absolute rounding of its neighbours: goldenutil.ATOL_LOG, soaks only)
-		near_zero = np.abs(o['dist_bayesfactor']) < 1e-3
-		np.testing.assert_allclose(q['dist_bayesfactor'][near_zero], o['dist_bayesfactor'][near_zero], rtol=RTOL, atol=ATOL_LOG)
-		q2 = dict(q, dist_bayesfactor=np.where(near_zero, o['dist_bayesfactor'], q['dist_bayesfactor']))
-		compare(q2, o, names)
+		# (near-zero log Bayes factors and, with the script's float32 numerics, float32 rounding flips: goldenutil.soak_compare)
+		flips += soak_compare(q, o, names, f32=f32)
 		rows += len(q['ncat'])
 		tails[q['_desc']['tail']] = tails.get(q['_desc']['tail'], 0) + 1
 		groups = np.bincount(q['P'].astype(np.int64), minlength=n0)
@@ -87,4 +84,4 @@ for seed in range(lo, hi):
 	except AssertionError as e:
 		bad.append(seed)
 		print('seed %d FAILED (n0=%d ns=%d lambda=%.4f frac=%.2f crowd=%d): %s' % (seed, n0, ns, lam, frac, crowd, " | ".join(str(e).strip().splitlines()[:12])[:900]), flush=True)
-print('%d configurations, %d rows, tails %s, %d failures %s in %.0f s' % (hi - lo, rows, tails, len(bad), bad, time.time() - t0))
+print('%d configurations, %d rows, tails %s, %d failures %s, %d rows excused as float32 rounding flips, in %.0f s' % (hi - lo, rows, tails, len(bad), bad, flips, time.time() - t0))
