@@ -248,6 +248,54 @@ def make_workload3(n0, n1, n2, seed):
 	return out
 
 
+def live_traffic(argv_tail, n_secondary, budget_s=150.0):
+	"""HBM bytes per launch of the sweep, MEASURED in this run: two child processes of this very script (a few steps, no CPU legs) under
+	`rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes: the two TCC counters do not fit one, and --pmc is never combined
+	with other traces), corrected as MI355X_MICROARCH.md prescribes -- KiB * 1024; gfx950 reports exactly half of a wide (16 B per lane)
+	coalesced streaming read, so the stream's uncounted half is added back (the kernel's gathers are counted in full).  Returns (bytes,
+	source) or (None, why not)."""
+	import csv
+	import glob
+	import shutil
+	import subprocess
+	import tempfile
+	prof = shutil.which('rocprofv3') or ('/opt/rocm/bin/rocprofv3' if os.path.exists('/opt/rocm/bin/rocprofv3') else None)
+	if prof is None:
+		return None, 'rocprofv3 not found'
+	out = tempfile.mkdtemp(prefix='nway_bench_pmc_')
+	t0 = time.perf_counter()
+	vals = {}
+	try:
+		for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
+			left = budget_s - (time.perf_counter() - t0)
+			if left < 20:
+				return None, 'time budget of the counter passes spent'
+			cmd = [prof, '--pmc', counter, '--output-format', 'csv', '-d', os.path.join(out, counter), '--', sys.executable, os.path.abspath(__file__),
+				'--steps', '6', '--warmup', '2', '--prewarm', '20', '--cpu-sample', '0', '--two-pipelines', '0', '--live-traffic', '0'] + argv_tail
+			env = dict(os.environ, TMPDIR='/tmp')
+			res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, timeout=left, cwd='/tmp', env=env)
+			files = glob.glob(os.path.join(out, counter, '*', '*counter_collection.csv'))
+			if res.returncode != 0 or not files:
+				return None, 'rocprofv3 --pmc %s failed (rc %d): %s' % (counter, res.returncode, res.stdout[-200:].replace('\n', ' '))
+			per = []
+			for r in csv.DictReader(open(files[0])):
+				if 'k_sweep' in r['Kernel_Name'] and r['Counter_Name'] == counter:
+					per.append(float(r['Counter_Value']))
+			if not per:
+				return None, 'no k_sweep dispatch in the %s pass' % counter
+			vals[counter] = sum(per) / len(per)
+	except Exception as e:
+		return None, '%s: %s' % (type(e).__name__, e)
+	finally:
+		shutil.rmtree(out, ignore_errors=True)
+	raw = vals['FETCH_SIZE'] * 1024
+	stream = 16.0 * n_secondary
+	fetch = raw + stream / 2 if raw >= stream / 2 else 2 * raw
+	return fetch + vals['WRITE_SIZE'] * 1024, ('measured in this run: child processes of this script under rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE '
+		'(separate passes), mean per k_sweep dispatch: FETCH %.0f KiB raw + the uncounted half of the 16 B/lane stream (gfx950), WRITE %.0f KiB; %.0f s'
+		% (vals['FETCH_SIZE'], vals['WRITE_SIZE'], time.perf_counter() - t0))
+
+
 def job_bytes(sizes, error_columns, rows):
 	"""algorithmic bytes of a whole JOB: every input column once, every output column once"""
 	k = len(sizes)
@@ -391,6 +439,8 @@ def main():
 		help='who carries the exchanges of the multi-GPU modes: torch.distributed (default) or the library\'s own RCCL calls behind the C ABI (nwayhip_comm_*)')
 	ap.add_argument('--extras', type=int, default=int(os.environ.get('NWAY_BENCH_EXTRAS', '1')),
 		help='N > 1: also measure, in the same launch, the fixed-size jobs BASELINE names for several GPUs (extra_configs: C3-S as one job, configs[3], configs[4]; both sharding modes, both carriers of the exchanges); 0 = skip')
+	ap.add_argument('--live-traffic', type=int, default=int(os.environ.get('NWAY_BENCH_LIVE_TRAFFIC', '1')),
+		help='N = 1: measure roofline.traffic in this run (two short child runs under rocprofv3 --pmc, ~30 s); 0: the recorded profiles/sweep_traffic.json')
 	ap.add_argument('--streams', type=int, default=int(os.environ.get('NWAY_BENCH_STREAMS', '1')),
 		help='independent pipelines (own workspace, own output table, own HIP stream) the steps alternate over')
 	args = ap.parse_args()
@@ -583,8 +633,16 @@ def main():
 		alg_bytes = 16.0 * n_sec_swept
 		achieved = alg_bytes / (sweep_ms * 1e-3) / 1e9 if sweep_ms > 0 else 0.0
 		traffic, traffic_source = None, None
+		live_note = None
+		under_profiler = any(k.startswith(('ROCPROF', 'ROCP_', 'ROCTX')) for k in os.environ)  # (a run that is itself being profiled does not start profilers)
+		if args.live_traffic and engine is None and world == 1 and args.cpu_sample != 0 and not under_profiler:
+			tail = ['--n-primary', str(args.n_primary), '--n-secondary', str(args.n_secondary), '--radius', str(args.radius), '--completeness', str(args.completeness),
+				'--seed', str(args.seed), '--sec-buffers', str(args.sec_buffers)]
+			traffic, traffic_source = live_traffic(tail, n_sec_swept)
+			if traffic is None:
+				live_note, traffic_source = traffic_source, None
 		tf = os.path.join(ROOT, 'profiles', 'sweep_traffic.json')
-		if os.path.exists(tf):
+		if traffic is None and os.path.exists(tf):
 			try:
 				rec = json.load(open(tf))
 				if rec.get('n_secondary') == n_sec_swept:
@@ -597,6 +655,8 @@ def main():
 						'STALE -- the kernel sources of this tree differ from the measured build (rerun tools/profile_round.sh)'))
 			except Exception:
 				traffic = None
+			if traffic_source and live_note:
+				traffic_source += ' [live measurement not available: %s]' % live_note
 		# the whole pass, SURVEY 8(d): rank 0's pass (its primaries, the secondaries it streams, its rows)
 		local_rows = int(st[_hip.ST_ROWS])
 		if engine is None:

@@ -129,3 +129,28 @@ def test_fits_roundtrip(tmp_path):
 def test_xmm_fixture_is_the_shipped_catalogue():
 	g = golden('xmm_inputs')
 	assert len(g['RA']) == 1797 and g['pos_err'].dtype == np.float32 and float(g['area'][0]) == 2.0
+
+
+def test_bench_live_traffic_degrades_gracefully(monkeypatch, tmp_path):
+	"""bench.py measures roofline.traffic itself (child runs under rocprofv3 --pmc); where that cannot work -- no profiler, no GPU, a
+	counter pass that fails -- it says why and the caller falls back to the recorded figure: never an exception, never a guess"""
+	import bench
+	# (a) no rocprofv3 at all
+	monkeypatch.setattr('shutil.which', lambda name: None)
+	monkeypatch.setattr('os.path.exists', lambda p, _real=os.path.exists: False if p == '/opt/rocm/bin/rocprofv3' else _real(p))
+	traffic, why = bench.live_traffic([], 1000)
+	assert traffic is None and 'not found' in why
+	monkeypatch.undo()
+	# (b) a profiler that runs and fails (stand-in script): the reason is reported
+	fake = tmp_path / 'rocprofv3'
+	fake.write_text('#!/bin/sh\necho no device >&2\nexit 7\n')
+	fake.chmod(0o755)
+	monkeypatch.setattr('shutil.which', lambda name: str(fake))
+	traffic, why = bench.live_traffic([], 1000, budget_s=30.0)
+	assert traffic is None and 'rc 7' in why
+	# (c) a profiler whose passes report 100 000 KiB fetched and 5 000 KiB written per k_sweep dispatch: the guide's correction
+	fake.write_text('#!/bin/sh\nwhile [ "$1" != "--pmc" ]; do shift; done; c=$2; while [ "$1" != "-d" ]; do shift; done; d=$2\n'
+		'mkdir -p $d/host; v=100000; [ "$c" = WRITE_SIZE ] && v=5000\n'
+		"printf '\"Kernel_Name\",\"Counter_Name\",\"Counter_Value\"\\n\"void k_sweep<1, true, true>(SweepArgs)\",\"%s\",%s\\n\"k_tail2(Tail2Args)\",\"%s\",1\\n' $c $v $c > $d/host/1_counter_collection.csv\n")
+	traffic, why = bench.live_traffic([], 10000000, budget_s=30.0)
+	assert traffic == 100000 * 1024 + 80e6 + 5000 * 1024 and why.startswith('measured in this run'), why
