@@ -105,6 +105,17 @@ def test_primary_shards_on_device(tmp_path, k, flat, cut):
 		np.testing.assert_allclose(got[c], o[c], rtol=RTOL, atol=ATOL, err_msg=c)
 
 
+def lopsided_catalogues():
+	"""3-way all-sky; the third catalogue lies in the southern sky only (a northern zone holds none of it), two sources without a declination"""
+	tabs = catalogues(3, False)
+	c = tabs[2]
+	south = c['dec'] < -20.0
+	tabs[2] = dict(c, ra=c['ra'][south].copy(), dec=c['dec'][south].copy(), error=c['error'][south].copy())
+	tabs[0]['dec'][5] = np.nan
+	tabs[1]['dec'][17] = np.nan
+	return tabs
+
+
 def zone_worker(rank, world, port, outfile, k, flat):
 	os.environ['MASTER_ADDR'] = '127.0.0.1'
 	os.environ['MASTER_PORT'] = str(port)
@@ -113,7 +124,7 @@ def zone_worker(rank, world, port, outfile, k, flat):
 	try:
 		sys.path.insert(0, ROOT)
 		from nway_amd import distributed
-		tabs = catalogues(k, flat)
+		tabs = catalogues(k, flat) if k > 0 else lopsided_catalogues()
 		dev = torch.device('cuda', 0)
 		torch.cuda.set_device(dev)
 		def rows(t, lo, hi):
@@ -126,6 +137,8 @@ def zone_worker(rank, world, port, outfile, k, flat):
 		zm = distributed.ZoneShardedMatch(parts[0], parts[1:], 10., 0.9, device=dev)
 		# the zone of a rank: about half of every catalogue (the edges are quantiles of the largest secondary catalogue)
 		assert 0.3 * len(tabs[1]['ra']) < zm.cats[1].n < 0.7 * len(tabs[1]['ra'])
+		if k == 0:
+			assert zm.cats[2].n == (0 if rank == 1 else len(tabs[2]['ra']))  # (the northern zone holds nothing of the third catalogue)
 		for _ in range(3):  # (repeated steps recycle the scratch copies)
 			zm.step()
 		total = zm.total_rows()
@@ -136,7 +149,7 @@ def zone_worker(rank, world, port, outfile, k, flat):
 		dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('k,flat', [(2, False), (3, False), (2, True), (3, True)])
+@pytest.mark.parametrize('k,flat', [(2, False), (3, False), (2, True), (3, True), (0, False)])
 def test_declination_zones_on_device(tmp_path, k, flat):
 	"""both sides sharded by declination zones (ZoneShardedMatch), two gloo ranks on the one GPU through the HIP pipeline: the
 	ranks' tables, concatenated and sorted by primary, equal the single-GPU table bit for bit (and the C oracle's)"""
@@ -145,7 +158,7 @@ def test_declination_zones_on_device(tmp_path, k, flat):
 	outfile = str(tmp_path / 'zones.npz')
 	mp.spawn(zone_worker, args=(2, free_port(), outfile, k, flat), nprocs=2, join=True)
 	got = np.load(outfile)
-	tabs = catalogues(k, flat)
+	tabs = catalogues(k, flat) if k > 0 else lopsided_catalogues()  # (k = 0: a zone without a catalogue, sources without a declination)
 	want = nw.nway_match(tabs, 10., 0.9, logger=nw.NullOutputLogger())
 	assert int(got['total']) == len(want) > len(tabs[0]['ra'])
 	assert 0.3 * len(want) < int(got['zone_rows']) < 0.7 * len(want)
