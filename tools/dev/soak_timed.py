@@ -1,6 +1,6 @@
 """development aid: tools/dev/soak.py with a time limit per configuration (a dense k = 5 case keeps
 the numpy oracle busy for minutes: skipped) and the time of every one
-    python tools/dev/soak_timed.py 400 800 [seconds per configuration]        (on the GPU box)
+    python tools/dev/soak_timed.py 400 800 [seconds per configuration]        (on the GPU box; SOAK_MISSING=1: NaN coordinates in the all-sky cases)
 """
 import os
 import signal
@@ -35,6 +35,14 @@ for seed in range(lo, hi):
 	if seed % 2 == 1 and k > 4:
 		tabs = tabs[:4]
 	comp = float(rng.choice([1.0, 0.9, 0.5]))
+	if os.environ.get('SOAK_MISSING') and seed % 2 == 1:
+		# sources without a coordinate (they match nothing and must not disturb the others): a few per catalogue, all-sky cases
+		for t in tabs:
+			for col in ('ra', 'dec'):
+				n = len(t[col])
+				if n > 8:
+					t[col] = np.array(t[col], dtype=float)
+					t[col][rng.choice(n, size=int(rng.integers(0, 4)), replace=False)] = np.nan
 	excused0 = fz.TIE_EXCUSES['rows']
 	t0 = time.time()
 	signal.alarm(limit)
