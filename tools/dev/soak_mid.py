@@ -43,6 +43,12 @@ for seed in range(lo, hi):
 		dec[:m] = np.clip(pdec[:m] + rng.normal(0, radius / 5, m) / 3600., -90, 90)
 		order = rng.permutation(ns)
 		tabs.append(cat('S%d' % c, ra[order] % 360 if whole_sky else ra[order], dec[order], float(rng.uniform(0.2, 1.0)) * np.ones(ns), area))
+	if os.environ.get('SOAK_MISSING') and whole_sky:
+		# sources without a coordinate: they match nothing and must not disturb the others (a NaN anywhere also means the all-sky scheme)
+		for t in tabs:
+			for col in ('ra', 'dec'):
+				t[col] = np.array(t[col], dtype=float)
+				t[col][rng.choice(len(t[col]), size=int(rng.integers(1, 6)), replace=False)] = np.nan
 	names = [t['name'] for t in tabs]
 	kw = dict(correction='cli') if (k > 2 and seed % 2 == 0) else {}
 	if os.environ.get('SOAK_CORR') == 'api':
