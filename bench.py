@@ -273,10 +273,21 @@ def live_traffic(argv_tail, n_secondary, budget_s=150.0):
 			cmd = [prof, '--pmc', counter, '--output-format', 'csv', '-d', os.path.join(out, counter), '--', sys.executable, os.path.abspath(__file__),
 				'--steps', '6', '--warmup', '2', '--prewarm', '20', '--cpu-sample', '0', '--two-pipelines', '0', '--live-traffic', '0'] + argv_tail
 			env = dict(os.environ, TMPDIR='/tmp')
-			res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, timeout=left, cwd='/tmp', env=env)
+			# (its own process group: a pass that overruns is killed with everything it started, nothing else)
+			proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, cwd='/tmp', env=env, start_new_session=True)
+			try:
+				stdout, _ = proc.communicate(timeout=left)
+			except subprocess.TimeoutExpired:
+				import signal
+				try:
+					os.killpg(proc.pid, signal.SIGKILL)
+				except OSError:
+					pass
+				proc.communicate()
+				return None, 'rocprofv3 --pmc %s did not finish in %.0f s' % (counter, left)
 			files = glob.glob(os.path.join(out, counter, '*', '*counter_collection.csv'))
-			if res.returncode != 0 or not files:
-				return None, 'rocprofv3 --pmc %s failed (rc %d): %s' % (counter, res.returncode, res.stdout[-200:].replace('\n', ' '))
+			if proc.returncode != 0 or not files:
+				return None, 'rocprofv3 --pmc %s failed (rc %d): %s' % (counter, proc.returncode, stdout[-200:].replace('\n', ' '))
 			per = []
 			for r in csv.DictReader(open(files[0])):
 				if 'k_sweep' in r['Kernel_Name'] and r['Counter_Name'] == counter:

@@ -154,3 +154,9 @@ def test_bench_live_traffic_degrades_gracefully(monkeypatch, tmp_path):
 		"printf '\"Kernel_Name\",\"Counter_Name\",\"Counter_Value\"\\n\"void k_sweep<1, true, true>(SweepArgs)\",\"%s\",%s\\n\"k_tail2(Tail2Args)\",\"%s\",1\\n' $c $v $c > $d/host/1_counter_collection.csv\n")
 	traffic, why = bench.live_traffic([], 10000000, budget_s=30.0)
 	assert traffic == 100000 * 1024 + 80e6 + 5000 * 1024 and why.startswith('measured in this run'), why
+	# (d) a pass that hangs: killed with its process group when the budget is spent
+	fake.write_text('#!/bin/sh\nsleep 300 &\nwait\n')
+	import time
+	t0 = time.time()
+	traffic, why = bench.live_traffic([], 1000, budget_s=22.0)
+	assert traffic is None and 'did not finish' in why and time.time() - t0 < 40
