@@ -176,6 +176,12 @@ int nwayhip_offsets(const double* a_ra, const double* a_dec, const double* b_ra,
 /* bayesdistance.py:26-32 (mode 0: posterior), :18-23 (mode 1: log_posterior),
  * :35-39 (mode 2: unnormalised_log_posterior) */
 int nwayhip_posterior(int32_t mode, const double* prior, const double* log_bf, int64_t n, double* out, void* stream);
+/* Test hook, no reference counterpart: the elementary functions the row kernels evaluate in place of the device library's
+ * (csrc/fastmath.inc: short roads for the arguments a match has), one call per element, so that they can be compared
+ * bit for bit with the same source compiled for the host and with numpy (numpy.sin, arctan2, hypot, log, log10, 10**x of
+ * fastskymatch.py:26-47 and bayesdistance.py:18-86).  fn: 0 sincos(x) -> out, out2; 1 atan2(x, y); 2 hypot(x, y);
+ * 3 log(x); 4 log10(x); 5 10^x.  y: only fn 1, 2; out2: only fn 0. */
+int nwayhip_fastmath_probe(int32_t fn, const double* x, const double* y, int64_t n, double* out, double* out2, void* stream);
 
 /* ---- the match pipeline ------------------------------------------------------------ */
 /* Replaces crossproduct (fastskymatch.py:92-218), _create_match_table (__init__.py:123-196),

@@ -87,6 +87,7 @@ SYMBOLS = {
 		ctypes.POINTER(_vp), _vp, _i32, _vp]),
 	'nwayhip_offsets': (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
 	'nwayhip_posterior': (ctypes.c_int, [_i32, _vp, _vp, _i64, _vp, _vp]),
+	'nwayhip_fastmath_probe': (ctypes.c_int, [_i32, _vp, _vp, _i64, _vp, _vp, _vp]),
 	'nwayhip_plan_create': (ctypes.c_int, [ctypes.POINTER(_vp), ctypes.POINTER(MatchParams), ctypes.POINTER(_i64), _i64, _i64]),
 	'nwayhip_plan_destroy': (ctypes.c_int, [_vp]),
 	'nwayhip_plan_workspace_bytes': (ctypes.c_size_t, [_vp]),

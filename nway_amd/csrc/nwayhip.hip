@@ -80,6 +80,7 @@ static void dev_launch_note(const char* name, int state, int line) {
 
 #pragma clang fp contract(off)
 
+#include "fastmath.inc"
 #include "common.inc"
 #include "sparse.inc"
 #include "front.inc"
