@@ -150,6 +150,18 @@ def test_three_way_with_the_scripts_correction_in_the_fused_tails():
 			crowd[c]['dec'][at:at + 14] = crowd[0]['dec'][i] + rng.normal(0, 2, size=14) / 3600.
 	t = both_paths(nw, crowd, 10.0, correction=_hip.CORRECTION_CLI, link_slots=31)
 	assert t['_path'] == _hip.PATH_SPARSE
+	# ... and groups of more than 64 rows whose workgroup's rows DO fit (the best offer of such a primary is found by a wave,
+	# taild3.inc): a few primaries with ten sources each in both catalogues, 121 rows
+	few = patch_tables(rng, [3000, 30000, 40000], 0.21, [1.0, 0.1, 0.5])
+	for c in (1, 2):
+		for i in range(5):
+			at = 2000 + 10 * i
+			few[c]['ra'][at:at + 10] = few[0]['ra'][100 * i] + rng.normal(0, 2, size=10) / 3600.
+			few[c]['dec'][at:at + 10] = few[0]['dec'][100 * i] + rng.normal(0, 2, size=10) / 3600.
+	t = both_paths(nw, few, 10.0, correction=_hip.CORRECTION_CLI)
+	assert t['_path'] == _hip.PATH_SPARSE and t['_link_slots'] > 8
+	groups = np.bincount(t['T0'].astype(np.int64))
+	assert groups.max() > 64
 
 
 def test_four_way_with_the_scripts_correction_fused_and_on_the_general_back_end(monkeypatch):
