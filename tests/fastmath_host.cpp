@@ -1,4 +1,4 @@
-// Host build of nway_amd/csrc/fastmath.inc for tests/test_fastmath_host.py: the functions use IEEE operations
+// Host build of nway_amd/csrc/fastmath.inc for tests/test_fastmath_host.py and test_fastmath.py (built by tests/fastmath_util.py): the functions use IEEE operations
 // only, so this is the arithmetic the kernels run (test infrastructure; not part of the library).
 #include <cmath>
 #define NW_FN static inline

@@ -12,12 +12,12 @@ _lib = None
 
 
 def host_library():
-	"""g++ -O2 -mfma -ffp-contract=off of the shim: IEEE operations in the order they are written, fused where the
+	"""g++ -O2 -ffp-contract=off of the shim (fma() is the C library's: the hardware's where there is one, exact either way): IEEE operations in the order they are written, fused where the
 	source says fma -- the arithmetic of the device build."""
 	global _lib
 	if _lib is None:
 		out = os.path.join(tempfile.mkdtemp(prefix='nway_fastmath_'), 'fastmath_host.so')
-		subprocess.check_call(['g++', '-O2', '-mfma', '-ffp-contract=off', '-fPIC', '-shared', '-o', out, os.path.join(HERE, 'fastmath_host.cpp')])
+		subprocess.check_call(['g++', '-O2', '-ffp-contract=off', '-fPIC', '-shared', '-o', out, os.path.join(HERE, 'fastmath_host.cpp')])
 		_lib = ctypes.CDLL(out)
 	return _lib
 
