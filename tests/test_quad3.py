@@ -103,6 +103,21 @@ def test_two_candidates_in_a_catalogue_stay_on_the_four_lanes(correction):
 	assert groups.max() == 9 and (groups > 4).sum() > 100 and (groups == 1).sum() > 0
 
 
+@pytest.mark.parametrize('correction', [False, True])
+def test_a_primary_catalogue_that_fills_the_chip_takes_the_wider_workgroups(correction):
+	"""65 536 primaries and more: workgroups of 512 threads (tail3q.inc: TAILQ_LARGE_FROM); the last workgroup partly filled"""
+	import nway_amd as nw
+	from nway_amd import _hip
+	rng = np.random.default_rng(31)
+	tabs = sky_tables(70001, 300000, 250000, 31)
+	crowded(tabs, rng, range(0, 400), 1, 1)
+	crowded(tabs, rng, range(300, 700), 2, 1)
+	crowded(tabs, rng, range(69900, 70001), 2, 1)
+	t = quad_and_lane(nw, tabs, 10.0, **(dict(correction=_hip.CORRECTION_CLI) if correction else {}))
+	groups = np.bincount(t['PRIM'].astype(np.int64), minlength=70001)
+	assert groups.max() >= 6 and (groups == 1).sum() > 0
+
+
 def test_three_candidates_in_a_catalogue_send_the_run_to_the_walk():
 	import nway_amd as nw
 	from nway_amd import _hip
