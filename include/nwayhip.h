@@ -180,7 +180,8 @@ int nwayhip_posterior(int32_t mode, const double* prior, const double* log_bf, i
  * (csrc/fastmath.inc: short roads for the arguments a match has), one call per element, so that they can be compared
  * bit for bit with the same source compiled for the host and with numpy (numpy.sin, arctan2, hypot, log, log10, 10**x of
  * fastskymatch.py:26-47 and bayesdistance.py:18-86).  fn: 0 sincos(x) -> out, out2; 1 atan2(x, y); 2 hypot(x, y);
- * 3 log(x); 4 log10(x); 5 10^x.  y: only fn 1, 2; out2: only fn 0. */
+ * 3 log(x); 4 log10(x); 5 10^x; 6 x / 180 * pi; 7 x * 180 / pi (the divisions by a literal, in three operations, correctly rounded).
+ * y: only fn 1, 2; out2: only fn 0. */
 int nwayhip_fastmath_probe(int32_t fn, const double* x, const double* y, int64_t n, double* out, double* out2, void* stream);
 
 /* ---- the match pipeline ------------------------------------------------------------ */

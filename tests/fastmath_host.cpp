@@ -10,5 +10,7 @@ void fm_atan2(const double* y, const double* x, double* o, long n) { for (long i
 void fm_hypot(const double* a, const double* b, double* o, long n) { for (long i = 0; i < n; ++i) o[i] = nw_hypot(a[i], b[i]); }
 void fm_log(const double* x, double* o, long n) { for (long i = 0; i < n; ++i) o[i] = nw_log(x[i]); }
 void fm_exp10(const double* x, double* o, long n) { for (long i = 0; i < n; ++i) o[i] = nw_exp10(x[i]); }
+void fm_radians(const double* x, double* o, long n) { for (long i = 0; i < n; ++i) o[i] = nw_radians(x[i]); }
+void fm_degrees(const double* x, double* o, long n) { for (long i = 0; i < n; ++i) o[i] = NW_DIV_K(x[i] * 180, M_PI); }
 void fm_log10(const double* x, double* o, long n) { for (long i = 0; i < n; ++i) o[i] = nw_log10(x[i]); }
 }

@@ -40,7 +40,7 @@ def host_eval(fn, x, y=None):
 		y = np.ascontiguousarray(y, dtype=np.float64)
 		(lib.fm_atan2 if fn == 1 else lib.fm_hypot)(_ptr(x), _ptr(y), _ptr(out), n)
 		return out
-	(lib.fm_log, lib.fm_log10, lib.fm_exp10)[fn - 3](_ptr(x), _ptr(out), n)
+	(lib.fm_log, lib.fm_log10, lib.fm_exp10, lib.fm_radians, lib.fm_degrees)[fn - 3](_ptr(x), _ptr(out), n)
 	return out
 
 
@@ -61,4 +61,6 @@ def arguments(n=20000, seed=3):
 	a[3] = (lg, None)
 	a[4] = (lg, None)
 	a[5] = (np.concatenate([rng.uniform(-30, 5, n), rng.uniform(-1, 1, n), rng.uniform(-330, 310, n), [0.0, 1.0, -1.0, 2.0, 308.0, -323.0, 400.0, -400.0, 1e300, -1e300], special]), None)
+	a[6] = (np.concatenate([rng.uniform(-360, 720, n), rng.uniform(-90, 90, n), 10 ** rng.uniform(-30, 30, n) * rng.choice([-1, 1], n), [0.0, -0.0, 180.0, 90.0, 360.0, -999.0, np.nan]]), None)
+	a[7] = (np.concatenate([rng.uniform(0, np.pi, n), 10 ** rng.uniform(-12, 0.5, n), [0.0, -0.0, np.pi, np.nan]]), None)
 	return a

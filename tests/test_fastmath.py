@@ -30,7 +30,7 @@ def same_bits(a, b):
 	return ((a.view(np.uint64) == b.view(np.uint64)) | nan)
 
 
-@pytest.mark.parametrize('fn', [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize('fn', [0, 1, 2, 3, 4, 5, 6, 7])
 def test_device_equals_host_build(fn):
 	x, y = arguments(200000, seed=11 + fn)[fn]
 	got = device_eval(fn, x, y)

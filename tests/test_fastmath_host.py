@@ -90,3 +90,15 @@ def test_exp10():
 	with np.errstate(all='ignore'):  # overflow, underflow, NaN as numpy has them; the smallest results within two steps
 		assert ((rest == want) | (np.isnan(rest) & np.isnan(want)) | (np.abs(rest - want) <= 2 * np.spacing(np.abs(want)))).all()
 	assert (host_eval(5, [0.0, 1.0, 2.0, 3.0, 22.0]) == [1.0, 10.0, 100.0, 1000.0, 1e22]).all()
+
+
+def test_divisions_by_a_literal_are_the_true_quotients():
+	"""x / 180 * pi and x * 180 / pi in three operations per division (fastmath.inc: nw_div_k): numpy's own expressions, bit for bit"""
+	x = arguments(500000, seed=8)[6][0]
+	got = host_eval(6, x)
+	want = x / 180 * np.pi
+	assert ((got.view(np.uint64) == want.view(np.uint64)) | (np.isnan(got) & np.isnan(want))).all()
+	x = arguments(500000, seed=9)[7][0]
+	got = host_eval(7, x)
+	want = x * 180 / np.pi
+	assert ((got.view(np.uint64) == want.view(np.uint64)) | (np.isnan(got) & np.isnan(want))).all()
