@@ -216,12 +216,21 @@ def soak_compare(t, o, names, f32=False):
 	  separation within a rounding error of the midpoint of two float32 values is rounded the other way by the other libm -- one
 	  float32 ulp (6e-8) of the separation, ~1e-6 of a posterior, about one row in a million.  Such rows (at most three per
 	  million, none beyond 1e-5) are counted and returned, not failed.
-	Index columns, ncat and match_flag stay bit-identical throughout.  Returns the number of excused rows."""
+	Index columns and ncat stay bit-identical throughout, match_flag too unless two rows of a primary tie in p_i to within rounding
+	(checked row by row below).  Returns the number of excused rows."""
 	assert len(t['ncat']) == len(o['ncat'])
 	for n in names:
 		np.testing.assert_array_equal(t[n], o[n])
 	np.testing.assert_array_equal(t['ncat'], o['ncat'])
-	np.testing.assert_array_equal(t['match_flag'], o['match_flag'])
+	flags = np.flatnonzero(np.asarray(t['match_flag']) != np.asarray(o['match_flag']))
+	if len(flags):
+		# identical unless two p_i of one primary are equal to within rounding (the allowance of tests/test_hip_fuzz.py: a tie of the
+		# INPUT -- e.g. two sources placed symmetrically about a primary -- decided by the last bit of two separations)
+		prim, pi = np.asarray(o[names[0]]), np.asarray(o['prob_this_match'], dtype=float)
+		for r in flags:
+			mine = np.sort(pi[prim == prim[r]])
+			tie = np.isclose(mine, mine[-1], rtol=1e-12).sum() > 1 or np.isclose(mine, 0.5 * mine[-1], rtol=1e-12).any()
+			assert tie, 'match_flag differs without a rounding-level tie (row %d)' % r
 	excused = np.zeros(len(o['ncat']), dtype=bool)
 	near_zero = np.abs(np.asarray(o['dist_bayesfactor'])) < 1e-3
 	cols = ['Separation_%s_%s' % (names[i], names[j]) for i in range(len(names)) for j in range(i + 1, len(names))]
