@@ -2,9 +2,10 @@
 arithmetic.  The functions are IEEE operations in a fixed order, so what is checked here is what the kernels compute
 (tests/test_fastmath.py compares the device with this build bit for bit).  Reference: numpy.sin / cos / arctan2 / hypot of
 fastskymatch.py:26-47, numpy.log / log10 / 10**x of bayesdistance.py:18-86."""
-import mpmath as mp
 import numpy as np
 import pytest
+
+mp = pytest.importorskip('mpmath')  # (50-digit arithmetic; comes with the image's sympy)
 
 from fastmath_util import arguments, host_eval
 
