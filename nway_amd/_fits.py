@@ -62,6 +62,7 @@ def _read_header(buf, off):
 	"""Parse header cards starting at byte ``off``; returns (ordered dict, new offset)."""
 	header = {}
 	comments = []
+	last = None  # the keyword a CONTINUE card (long-string convention) carries on
 	while True:
 		blk = buf[off:off + BLOCK]
 		if len(blk) < BLOCK:
@@ -76,8 +77,14 @@ def _read_header(buf, off):
 				break
 			if key in ('COMMENT', 'HISTORY'):
 				comments.append(card[8:].rstrip())
+			elif key == 'CONTINUE' and last is not None and isinstance(header[last], str):
+				# a string value too long for one card: every piece but the last ends in '&' (what astropy writes for
+				# the script's NWAYCMD, nway.py:644)
+				head = header[last]
+				header[last] = (head[:-1] if head.endswith('&') else head) + str(_parse_value(card[8:]))
 			elif card[8:10] == '= ':
 				header[key] = _parse_value(card[10:])
+				last = key
 		if done:
 			break
 	header['_COMMENTS'] = comments
@@ -216,6 +223,31 @@ def _card(key, value, comment=''):
 	return ('%-80s' % card)[:80]
 
 
+def _string_cards(key, value):
+	"""a string value as one card, or -- longer than a card holds -- as a card and CONTINUE cards (pieces of 67
+	characters, all but the last ending in '&': the long-string convention astropy follows)"""
+	text = str(value).replace("'", "''")
+	if len(text) <= 68:
+		return [_card(key, value)]
+	pieces = [text[i:i + 67] for i in range(0, len(text), 67)]
+	cards = []
+	for n, piece in enumerate(pieces):
+		body = "'%s%s'" % (piece, '&' if n + 1 < len(pieces) else '')
+		cards.append(('%-80s' % (('%-8s= ' % key[:8] if n == 0 else 'CONTINUE  ') + body))[:80])
+	return cards
+
+
+def read_header(filename, hdu=0):
+	"""the header of HDU number ``hdu`` as a dict (COMMENT / HISTORY texts under '_COMMENTS')"""
+	with open(filename, 'rb') as f:
+		buf = f.read()
+	off = 0
+	for index in range(hdu + 1):
+		header, off = _read_header(buf, off)
+		off += _pad(_data_size(header))
+	return header
+
+
 def _header_bytes(cards):
 	cards = list(cards) + ['%-80s' % 'END']
 	raw = ''.join(cards).encode('ascii', errors='replace')
@@ -280,7 +312,7 @@ def write_table(filename, columns, extname, primary_header=None, table_header=No
 	pcards = [_card('SIMPLE', True, 'Standard FITS format'), _card('BITPIX', 8), _card('NAXIS', 0),
 		_card('EXTEND', True), _card('DATE', now), _card('ANALYSIS', 'NWAY matching')]
 	for k, v in (primary_header or {}).items():
-		pcards.append(_card(k, v))
+		pcards += _string_cards(k, v) if isinstance(v, str) else [_card(k, v)]
 	for c in (comments or []):
 		c = str(c)
 		while True:

@@ -141,6 +141,7 @@ def cli_magnitude_bias(mag, magfile, table_names, tables, idx_columns, sep_max, 
 
 
 def main(argv=None):
+	argv_from_sys = argv is None
 	argv = list(sys.argv[1:] if argv is None else argv)
 	args = build_parser().parse_args(argv)
 	print('NWAY arguments:')
@@ -329,12 +330,12 @@ def main(argv=None):
 	print()
 	print('creating output FITS file ...')
 	header = dict(METHOD='NWAY multi-way matching', INPUT=', '.join(filenames), TABLES=', '.join(table_names),
-		BIASING=', '.join(biases), NWAYCMD=' '.join(['nway.py'] + argv)[:60])
+		BIASING=', '.join(biases), NWAYCMD=' '.join([sys.argv[0] if argv_from_sys else 'nway.py'] + argv))
 	header['COLS_RA'] = ' '.join('%s_%s' % (n, rk) for n, rk in zip(table_names, ra_keys))
 	header['COLS_DEC'] = ' '.join('%s_%s' % (n, dk) for n, dk in zip(table_names, dec_keys))
 	header['COL_PRIM'] = primary_id_key
 	header['COLS_ERR'] = ' '.join('%s_%s' % (n, e) for n, e in zip(table_names, pos_errors))
-	comments = ['argument %s: %s' % (key, value) for key, value in sorted(vars(args).items())]
+	comments = ['argument %s: %s' % (key, value) for key, value in vars(args).items()]  # the namespace's order, like nway.py:645
 	print('    writing "%s" (%d rows, %d columns) ...' % (args.out, len(columns[0][2]), len(columns)))
 	_fits.write_table(args.out, columns, 'NWAYMATCH', primary_header=header, comments=comments, overwrite=True)
 	return 0

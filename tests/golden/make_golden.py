@@ -207,47 +207,8 @@ def gen_ell():
 	res3 = run([tX, tR, tO], 10., 1.0)
 	out.update(checksums(res3, names3, 'c10_'))
 	out.update(subset_rows(res3, names3, 13, 'c10_'))
-	# CLI-behaviour correction (nway.py:366-420), evaluated by a literal transcription
-	# of that loop on the reference's own intermediate arrays
-	out.update(cli_correction(ref, [tX, tR, tO], 10., 1.0))
+	# (the script's unrelated-association correction on these files: make_script_golden.py, which executes nway.py itself)
 	save('ell3', **out)
-
-
-def cli_correction(ref, tables, radius, completeness):
-	"""nway.py:366-420 transcribed; consumes the reference's own separations/errors/log_bf."""
-	tables = [dict(t, ra=t['ra'].copy(), dec=t['dec'].copy(), error=t['error'].copy()) for t in tables]
-	table, resultstable, separations, errors = ref._create_match_table(tables, radius, logger=LOG)
-	dens, dens_plus = ref._compute_source_densities(tables, logger=LOG)
-	prior, log_bf = ref._compute_single_log_bf(tables, dens, dens_plus, table, separations, errors, completeness, logger=LOG)
-	bd = ref.bayesdist
-	ncat = table['ncat'].values
-	ncats = len(tables)
-	prim = resultstable[:, 0]
-	starts = np.flatnonzero(np.r_[True, prim[1:] != prim[:-1]])
-	ends = np.r_[starts[1:], len(prim)]
-	group_of = np.repeat(np.arange(len(starts)), ends - starts)
-	corrected = log_bf.copy()
-	for i in np.where(ncat <= ncats - 2)[0]:
-		missing_cats = [k for k, sep in enumerate(separations[0]) if np.isnan(sep[i])]
-		best_logpost = 0
-		g = group_of[i]
-		for j in range(starts[g], ends[g]):
-			if not (ncat[j] > 2):
-				continue
-			augmented_cats = [k for k in missing_cats if not np.isnan(separations[0][k][j])]
-			if len(augmented_cats) >= 2:
-				prior_j = dens[augmented_cats[0]] / np.prod(dens_plus[augmented_cats])
-				errors_selected = [[errors[k][j]] for k in augmented_cats]
-				separations_selected = [[[separations[k][k2][j]] for k2 in augmented_cats] for k in augmented_cats]
-				log_bf_j = bd.log_bf(np.array(separations_selected), np.array(errors_selected))
-				logpost_j = bd.unnormalised_log_posterior(prior_j, log_bf_j, len(augmented_cats))[0]
-				if logpost_j > best_logpost:
-					best_logpost = logpost_j
-		if best_logpost > 0:
-			corrected[i] += best_logpost
-	changed = np.flatnonzero(corrected != log_bf)
-	return dict(cli_changed_rows=changed, cli_correction=(corrected - log_bf)[changed],
-		cli_sum_correction=np.array([(corrected - log_bf).sum()]))
 
 
 def gen_xmm():
@@ -302,7 +263,6 @@ def gen_edge():
 	out['neg_completeness'] = np.array([1.0, 0.8, 0.6])
 	out['neg_crossproduct'] = cp.astype(np.int32)
 	out.update(table_arrays(res, names, 'neg_'))
-	out.update(cli_correction_prefixed(ref, [t0, t1, t2], r, np.array([1.0, 0.8, 0.6]), 'neg_'))
 	# (2) exact ties: two secondaries mirrored in RA about the primary (bit-equal separations are
 	#     not guaranteed; whatever the reference says is the expected answer) + a duplicate secondary
 	p_ra, p_dec = np.array([100.0, 100.5]), np.array([10.0, 10.0])
@@ -337,10 +297,6 @@ def gen_edge():
 	out['k4_crossproduct_rows_per_primary'] = np.bincount(cp[:, 0], minlength=25).astype(np.int32)
 	out.update(table_arrays(res, ['T0', 'T1', 'T2', 'T3'], 'k4_'))
 	save('edge', **out)
-
-
-def cli_correction_prefixed(ref, tables, radius, completeness, prefix):
-	return dict((prefix + k, v) for k, v in cli_correction(ref, tables, radius, completeness).items())
 
 
 if __name__ == '__main__':
@@ -504,74 +460,12 @@ def gen_allsky():
 	out['w3_crossproduct_nrows'] = np.array([len(cp)])
 	res = run([ta, tb, tc], radius, 0.9)
 	out.update(table_arrays(res, ['A', 'B', 'C'], 'w3_'))
-	out.update(cli_correction_prefixed(ref, [ta, tb, tc], radius, 0.9, 'w3_'))
 	print('allsky: 2-way %d rows, 3-way %d rows (pre-filter %d)' % (len(out['w2_idx']), len(out['w3_idx']), len(cp)))
 	save('allsky', **out)
 
 
 if __name__ == '__main__' and ('allsky' in sys.argv[1:] or not sys.argv[1:]):
 	gen_allsky()
-
-
-def script_numerics(tables, radius, completeness, prob_ratio_secondary=0.5, consider_unrelated_associations=True):
-	"""The numbers the SCRIPT nway.py would compute, assembled from the reference's
-	own functions: the separations make the trip through a float32 FITS column
-	(fastskymatch.py:328, nway.py:283-302) before _compute_single_log_bf (== nway.py:327-360) and
-	the correction loop of nway.py:366-420 (restated in cli_correction above) see them."""
-	table, resultstable, separations, errors = ref._create_match_table(tables, radius, logger=LOG)
-	sep32 = [[cell.astype(np.float32) if i < j else cell for j, cell in enumerate(row)] for i, row in enumerate(separations)]
-	dens, dens_plus = ref._compute_source_densities(tables, logger=LOG)
-	prior, log_bf = ref._compute_single_log_bf(tables, dens, dens_plus, table, sep32, errors, completeness, logger=LOG)
-	bd = ref.bayesdist
-	ncat = table['ncat'].values
-	ncats = len(tables)
-	prim = resultstable[:, 0]
-	starts = np.flatnonzero(np.r_[True, prim[1:] != prim[:-1]])
-	ends = np.r_[starts[1:], len(prim)]
-	group_of = np.repeat(np.arange(len(starts)), ends - starts)
-	corrected = log_bf.copy()
-	for i in (np.where(ncat <= ncats - 2)[0] if consider_unrelated_associations else []):
-		missing_cats = [k for k, sep in enumerate(sep32[0]) if np.isnan(sep[i])]
-		best_logpost = 0
-		g = group_of[i]
-		for j in range(starts[g], ends[g]):
-			if not (ncat[j] > 2):
-				continue
-			augmented_cats = [k for k in missing_cats if not np.isnan(sep32[0][k][j])]
-			if len(augmented_cats) >= 2:
-				prior_j = dens[augmented_cats[0]] / np.prod(dens_plus[augmented_cats])
-				errors_selected = [[errors[k][j]] for k in augmented_cats]
-				separations_selected = [[[sep32[k][k2][j]] for k2 in augmented_cats] for k in augmented_cats]
-				log_bf_j = bd.log_bf(np.array(separations_selected), np.array(errors_selected))
-				logpost_j = bd.unnormalised_log_posterior(prior_j, log_bf_j, len(augmented_cats))[0]
-				if logpost_j > best_logpost:
-					best_logpost = logpost_j
-		if best_logpost > 0:
-			corrected[i] += best_logpost
-	table = table.assign(dist_bayesfactor_uncorrected=log_bf, dist_bayesfactor=corrected, dist_post=bd.posterior(prior, corrected))
-	return ref._compute_final_probabilities(tables, table, prob_ratio_secondary, prior, corrected, logger=LOG)
-
-
-def gen_f32():
-	"""edge.npz's 3-way tables (cells straddling Dec = 0) and their first two catalogues with the
-	script's numerics; the inputs are read back from edge.npz"""
-	g = np.load(os.path.join(HERE, 'edge.npz'))
-	tabs = [cat('ABC'[i], g['neg_ra%d' % i], g['neg_dec%d' % i], g['neg_err%d' % i], float(g['neg_area'][0])) for i in range(3)]
-	radius = float(g['neg_radius'][0])
-	out = {}
-	res = script_numerics(tabs, radius, g['neg_completeness'])
-	out.update(table_arrays(res, ['A', 'B', 'C'], 'w3_'))
-	res2 = script_numerics(tabs[:2], radius, g['neg_completeness'][:2])
-	out.update(table_arrays(res2, ['A', 'B'], 'w2_'))
-	api = run(tabs, radius, g['neg_completeness'])
-	out['w3_max_rel_change_of_p_i'] = np.array([np.nanmax(np.abs(res['prob_this_match'].values - api['prob_this_match'].values)
-		/ np.maximum(api['prob_this_match'].values, 1e-300))])
-	print('f32: %d / %d rows; p_i differs from the float64 API by up to %.2e relative' % (len(res), len(res2), out['w3_max_rel_change_of_p_i'][0]))
-	save('f32', **out)
-
-
-if __name__ == '__main__' and ('f32' in sys.argv[1:] or not sys.argv[1:]):
-	gen_f32()
 
 
 def mag3_catalogues(xmm_ra, xmm_dec, seed, n_opt, n_irac, k_opt, k_irac):
@@ -687,9 +581,7 @@ def gen_kway():
 		res = run(tabs, radius, comp)
 		out[tag + '_area'] = np.array([span**2]); out[tag + '_radius'] = np.array([radius]); out[tag + '_completeness'] = np.atleast_1d(comp)
 		out.update(table_arrays(res, names, tag + '_'))
-		out.update(cli_correction_prefixed(ref, tabs, radius, comp, tag + '_'))
-		out.update(table_arrays(script_numerics(tabs, radius, comp), names, tag + '_script_'))
-		print('%s: %d rows, ncat %s, %d rows corrected (sum %.6f)' % (tag, len(res), np.bincount(res['ncat'].values), len(out[tag + '_cli_changed_rows']), out[tag + '_cli_sum_correction'][0]))
+		print('%s: %d rows, ncat %s' % (tag, len(res), np.bincount(res['ncat'].values)))
 	save('kway', **out)
 
 
@@ -734,134 +626,15 @@ def gen_kmulti():
 		res = run(tabs, radius, comp)
 		out[tag + '_area'] = np.array([area]); out[tag + '_radius'] = np.array([radius]); out[tag + '_completeness'] = np.atleast_1d(comp)
 		out.update(table_arrays(res, names, tag + '_'))
-		out.update(cli_correction_prefixed(ref, tabs, radius, comp, tag + '_'))
 		groups = np.bincount(res[names[0]].values)
-		print('%s: %d rows, ncat %s, largest group %d, primaries with two sources in >= 2 catalogues: %d, %d rows corrected' % (
-			tag, len(res), np.bincount(res['ncat'].values), groups.max(), (multi >= 2).sum(), len(out[tag + '_cli_changed_rows'])))
+		print('%s: %d rows, ncat %s, largest group %d, primaries with two sources in >= 2 catalogues: %d' % (
+			tag, len(res), np.bincount(res['ncat'].values), groups.max(), (multi >= 2).sum()))
 		assert (multi >= 2).sum() >= 100
 	save('kmulti', **out)
 
 
 if __name__ == '__main__' and ('kmulti' in sys.argv[1:] or not sys.argv[1:]):
 	gen_kmulti()
-
-
-def script_mag_numerics(tables, radius, completeness, mag_include_radius=None, mag_exclude_radius=None, minprob=0.9,
-		prob_ratio_secondary=0.5):
-	"""What the SCRIPT computes with ``--mag T:col auto`` for every magnitude column of ``tables``:
-	script_numerics' float32 trip, then nway.py:430-527 transcribed (its selection indexes the
-	weights by the SELECTED rows, nway.py:471, where the API uses the defined ones; the
-	separation column it thresholds is the float32 one), then the reference's group statistics."""
-	bd = ref.bayesdist
-	if mag_exclude_radius is None:
-		mag_exclude_radius = mag_include_radius
-	table, resultstable, separations, errors = ref._create_match_table(tables, radius, logger=LOG)
-	sep32 = [[cell.astype(np.float32) if i < j else cell for j, cell in enumerate(row)] for i, row in enumerate(separations)]
-	dens, dens_plus = ref._compute_source_densities(tables, logger=LOG)
-	prior, log_bf = ref._compute_single_log_bf(tables, dens, dens_plus, table, sep32, errors, completeness, logger=LOG)
-	assert len(tables) == 3  # the correction only touches row 0 of a group; k = 3 closed form not needed: reuse the loop
-	ncat = table['ncat'].values
-	prim = resultstable[:, 0]
-	starts = np.flatnonzero(np.r_[True, prim[1:] != prim[:-1]])
-	ends = np.r_[starts[1:], len(prim)]
-	group_of = np.repeat(np.arange(len(starts)), ends - starts)
-	log_bf = log_bf.copy()
-	uncorrected = log_bf.copy()
-	for i in np.where(ncat <= len(tables) - 2)[0]:
-		missing_cats = [k for k, sep in enumerate(sep32[0]) if np.isnan(sep[i])]
-		best_logpost = 0
-		g = group_of[i]
-		for j in range(starts[g], ends[g]):
-			if not (ncat[j] > 2):
-				continue
-			augmented_cats = [k for k in missing_cats if not np.isnan(sep32[0][k][j])]
-			if len(augmented_cats) >= 2:
-				prior_j = dens[augmented_cats[0]] / np.prod(dens_plus[augmented_cats])
-				errors_selected = [[errors[k][j]] for k in augmented_cats]
-				separations_selected = [[[sep32[k][k2][j]] for k2 in augmented_cats] for k in augmented_cats]
-				log_bf_j = bd.log_bf(np.array(separations_selected), np.array(errors_selected))
-				logpost_j = bd.unnormalised_log_posterior(prior_j, log_bf_j, len(augmented_cats))[0]
-				if logpost_j > best_logpost:
-					best_logpost = logpost_j
-		if best_logpost > 0:
-			log_bf[i] += best_logpost
-	post = bd.posterior(prior, log_bf)
-	sep_max32 = table['Separation_max'].values.astype(np.float32)
-	biases, hist_texts = {}, {}
-	for ti, t in enumerate(tables):
-		res = resultstable[:, ti]
-		res_defined = res != -1
-		for magvals, magname in zip(t['mags'], t['magnames']):
-			col = '%s_%s' % (t['name'], magname)
-			table_col = np.where(res_defined, magvals[res], -99.)  # match_multiple: gathered, -99 where missing
-			mag_all = magvals
-			mag_all[mag_all == -99] = np.nan
-			mask_all = ~np.logical_or(np.isnan(mag_all), np.isinf(mag_all))
-			if mag_include_radius is not None:
-				selection = sep_max32 < mag_include_radius
-				selection_possible = sep_max32 < mag_exclude_radius
-				selection_weights = np.ones(len(selection))
-			else:
-				selection = post > minprob
-				selection_weights = post
-				selection_possible = post > 0.01
-			selection = np.logical_and(selection, res_defined)
-			selection_weights = selection_weights[selection]
-			selection_possible = np.logical_and(selection_possible, res_defined)
-			rows, unique_indices = np.unique(res[selection], return_index=True)
-			rows_weights = selection_weights[unique_indices]
-			assert len(rows) > 1
-			mag_sel = mag_all[rows]
-			rows_possible = np.unique(res[selection_possible])
-			mask_others = mask_all.copy()
-			mask_others[rows_possible] = False
-			mask_sel = ~np.logical_or(np.isnan(mag_sel), np.isinf(mag_sel))
-			bins, hist_sel, hist_all = ref.magnitudeweights.adaptive_histograms(mag_all[mask_others], mag_sel[mask_sel], weights=rows_weights[mask_sel])
-			import io
-			f = io.BytesIO()
-			f.write(b'# lo hi selected others\n')
-			np.savetxt(f, np.transpose([bins[:-1], bins[1:], hist_sel, hist_all]), fmt=['%10.5f'] * 4)
-			hist_texts[col] = f.getvalue()
-			func = ref.magnitudeweights.fitfunc_histogram(bins, hist_sel, hist_all)
-			with np.errstate(divide='ignore'):
-				weights = np.log10(func(table_col))
-			weights[np.isnan(weights)] = 0
-			biases[col] = weights
-	total = log_bf + sum(biases.values())
-	table = table.assign(dist_bayesfactor_uncorrected=uncorrected, dist_bayesfactor=log_bf, dist_post=post)
-	final = ref._compute_final_probabilities(tables, table, prob_ratio_secondary, prior, total, logger=LOG)
-	return final, dict((c, 10**w) for c, w in biases.items()), hist_texts
-
-
-def gen_magscript():
-	"""the command line's magnitude priors (--mag T:col auto, by posterior and by radius) on the
-	mag3 catalogues; expected FITS column values are these cast to float32"""
-	from goldenutil import mag3_tables
-	out = {}
-	names = ['XMM', 'OPT', 'IRAC']
-	for tag, kw in (('post', dict()), ('rad', dict(mag_include_radius=3.3))):
-		final, biases, texts = script_mag_numerics(mag3_tables(), 20., 0.9, **kw)
-		out.update(checksums(final, names, tag + '_'))
-		out.update(subset_rows(final, names, 17, tag + '_'))
-		mask = (final['XMM'].values % 17) == 0
-		for col, v in biases.items():
-			out['%s_sum_bias_%s' % (tag, col)] = np.array([v.sum()])
-			out['%s_sub_bias_%s' % (tag, col)] = v[mask]
-			out['%s_hist_%s' % (tag, col)] = np.frombuffer(texts[col], dtype=np.uint8)
-		print('magscript %s: %d rows, flags %s' % (tag, len(final), np.bincount(final['match_flag'].values)))
-	# the other switches of the command line, without magnitudes: --ignore-unrelated-associations
-	# --prior-completeness 0.9:0.8 --acceptable-prob 0.2 --min-prob 0.05
-	plain = [cat(t['name'], t['ra'], t['dec'], t['error'], t['area']) for t in mag3_tables()]
-	final = script_numerics(plain, 20., np.array([1.0, 0.9, 0.8]), prob_ratio_secondary=0.2, consider_unrelated_associations=False)
-	final = final[~(final['prob_this_match'] < 0.05)]
-	out.update(table_arrays(final, names, 'opts_'))
-	print('magscript opts: %d rows, flags %s' % (len(final), np.bincount(final['match_flag'].values)))
-	save('magscript', **out)
-
-
-if __name__ == '__main__' and ('magscript' in sys.argv[1:] or not sys.argv[1:]):
-	sys.path.insert(0, os.path.dirname(HERE))
-	gen_magscript()
 
 
 def fuzz_case(seed):
@@ -946,11 +719,6 @@ def gen_fuzz(nseeds=35):
 			out.update(table_arrays(res, names, tag))
 			if tabs[-1]['mags']:
 				out[tag + 'bias'] = res['bias_%s_M' % names[-1]].values
-			else:
-				# the same configuration with the script's numerics and its correction loop
-				plain = [cat(t['name'], t['ra'], t['dec'], t['error'], t['area']) for t in tabs]
-				sres = script_numerics(plain, radius, comp, prob_ratio_secondary=opts['prob_ratio_secondary'])
-				out.update(table_arrays(sres, names, tag + 'script_'))
 			print('fuzz %2d: k=%d %s rows=%d flags=%s' % (seed, len(tabs), ['flat', 'flat', 'flat', 'north', 'seam', 'south', 'high'][seed % 7], len(res), np.bincount(res['match_flag'].values, minlength=3)))
 	finally:
 		os.chdir(cwd)
@@ -1046,8 +814,6 @@ def gen_sparse():
 			comp = out['completeness'][:k]
 			res = run(moved[:k], 6., comp)
 			out.update(table_arrays(res, names[:k], tag))
-			sres = script_numerics(moved[:k], 6., comp)
-			out.update(table_arrays(sres, names[:k], tag + 'script_'))
 			print('sparse %s k=%d: %d rows, ncat %s' % (where, k, len(res), np.bincount(res['ncat'].values)))
 	save('sparse', **out)
 

@@ -1,0 +1,405 @@
+#!/usr/bin/env python
+"""Golden vectors made by EXECUTING THE REFERENCE'S SCRIPT, /root/reference/nway.py.
+
+Build container only (needs /root/reference; listed in .gpurunignore):
+
+    python tests/golden/make_script_golden.py [cli] [api]
+
+astropy is absent from this image; ``fits_standin.py`` (an I/O-only stand-in for
+``astropy.io.fits``, see its header for the two copy semantics it states) is registered in its
+place and the script is run unmodified with ``runpy`` under a chosen ``sys.argv``.  Nothing of
+the script is restated here: every number in the fixtures was computed by nway.py and nwaylib.
+
+Two families:
+
+``script_cli.npz`` + ``script_cli.json``  -- command lines on FITS catalogues: the reference's own
+    tests/elltest/randomcat{X,R,O}.fits (copied byte for byte to tests/golden/elltest/ so that the
+    product's command line reads the very same files) and doc/COSMOS_XMM.fits with seeded
+    stand-ins for the two catalogues missing from the checkout, with magnitude columns.  Recorded:
+    the table the script WRITES (column names, order, TFORMs; every computed column as stored,
+    float32 / int16), the header keys of both HDUs, the COMMENT cards, the ``*_fit.txt`` histogram
+    files.
+``script_api.npz`` -- the script run on the INPUTS of the API fixtures (edge / kway / fuzz / sparse /
+    xmm_syn / ell3) written to FITS: what ``nway_amd.nway_match(..., unrelated_associations='cli',
+    f32_roundtrip=True)`` has to reproduce.  Stored under the key layout of make_golden.table_arrays
+    (``{tag}script_*``); float64 where the script holds the quantity in float64 at exit
+    (``log_bf``, ``post``, ``prob_has_match``, ``prob_this_match``), float32 where the script itself
+    only ever has float32 (the separations after their trip through the 'E' columns,
+    fastskymatch.py:328).  The uncorrected Bayes factors in float64 come from a second run with
+    ``--ignore-unrelated-associations``; their difference to the first run's is the correction
+    (``{tag}cli_changed_rows``, ``{tag}cli_correction``).
+
+The HEALPix branch (inputs near the poles / the RA seam / |Dec| >= 45) needs healpy: oracle/healpix.py
+stands in (pins the branch logic, not healpy's numbering -- as for every all-sky fixture).
+"""
+import contextlib
+import io
+import json
+import os
+import runpy
+import shutil
+import sys
+import tempfile
+import time
+import warnings
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REFERENCE = '/root/reference'
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+import fits_standin  # noqa: E402
+
+warnings.simplefilter('ignore')
+fits_standin.install(healpix=True)
+import matplotlib  # noqa: E402
+matplotlib.use('Agg')
+
+SCRATCH = tempfile.mkdtemp(prefix='nwayscript_')
+os.chdir(SCRATCH)
+# nwaylib/checkupdates.py:14 -- no look-up on PyPI from here
+open('I_will_check_for_NWAY_updates_myself_thank_you', 'w').close()
+sys.path.insert(0, REFERENCE)
+
+
+def run_script(argv, quiet=True):
+	"""execute the reference's nway.py; returns (its module globals at exit, what it printed)"""
+	old = sys.argv
+	sys.argv = ['nway.py'] + [str(a) for a in argv]
+	buf = io.StringIO()
+	err = io.StringIO()
+	t0 = time.time()
+	try:
+		with contextlib.redirect_stdout(buf), contextlib.redirect_stderr(err):
+			g = runpy.run_path(os.path.join(REFERENCE, 'nway.py'), run_name='__main__')
+	except BaseException:
+		sys.stderr.write(buf.getvalue()[-3000:])
+		raise
+	finally:
+		sys.argv = old
+	if not quiet:
+		print(buf.getvalue())
+	g['__seconds__'] = time.time() - t0
+	return g, buf.getvalue()
+
+
+def save(name, **arrays):
+	path = os.path.join(HERE, name + '.npz')
+	np.savez_compressed(path, **arrays)
+	print('%-14s %8.1f KB  %d arrays' % (name, os.path.getsize(path) / 1024., len(arrays)))
+
+
+def native(a):
+	"""a FITS (big-endian) column as a native-endian array of the same type"""
+	a = np.asarray(a)
+	return a.astype(a.dtype.newbyteorder('='))
+
+
+def completeness_argument(comp):
+	comp = np.atleast_1d(comp)
+	if len(comp) == 1:
+		return repr(float(comp[0]))
+	assert comp[0] == 1.0
+	return ':'.join(repr(float(c)) for c in comp[1:])
+
+
+# ---------------------------------------------------------------------------
+# the script on in-memory tables (the API fixtures' inputs)
+
+def write_tables(tabs, prefix):
+	files = []
+	for t in tabs:
+		n = len(t['ra'])
+		cols = [('ID', 'J', np.arange(n)), ('RA', 'D', t['ra']), ('DEC', 'D', t['dec']), ('pos_err', 'D', np.asarray(t['error'], dtype=float))]
+		for name, mag in zip(t.get('magnames', []), t.get('mags', [])):
+			cols.append((name, 'D', mag))
+		fn = '%s%s.fits' % (prefix, t['name'])
+		fits_standin.write_catalogue(fn, t['name'], t['area'], cols)
+		files.append(fn)
+	return files
+
+
+def script_table(tabs, radius, comp, ratio=0.5, tag='case', extra=()):
+	"""run nway.py on the tables (and, for three or more catalogues, once more without the
+	correction); returns the arrays of one fixture entry"""
+	names = [t['name'] for t in tabs]
+	k = len(tabs)
+	files = write_tables(tabs, tag)
+	argv = ['--radius', repr(float(radius)), '--prior-completeness', completeness_argument(comp), '--acceptable-prob', repr(float(ratio))]
+	for f in files:
+		argv += [f, ':pos_err']
+	argv += list(extra)
+	g, log = run_script(argv + ['--out', tag + 'out.fits'])
+	out = fits_standin.open(tag + 'out.fits')[1].data
+	res = {}
+	idx = np.stack([np.where(native(out['%s_ID' % n]) == -99, -1, native(out['%s_ID' % n])) for n in names], axis=1).astype(np.int32)
+	res['idx'] = idx
+	for i in range(k):
+		for j in range(i + 1, k):
+			res['sep_%d_%d' % (i, j)] = native(out['Separation_%s_%s' % (names[j], names[i])])
+	res['Separation_max'] = native(out['Separation_max'])
+	res['ncat'] = native(out['ncat']).astype(np.int8)
+	res['match_flag'] = native(out['match_flag']).astype(np.int8)
+	assert (res['match_flag'] == g['index']).all()
+	res['dist_bayesfactor'] = np.array(g['log_bf'], dtype=float)
+	if k >= 3:
+		g0, _ = run_script(argv + ['--ignore-unrelated-associations', '--out', tag + 'out0.fits'])
+		res['dist_bayesfactor_uncorrected'] = np.array(g0['log_bf'], dtype=float)
+		delta = res['dist_bayesfactor'] - res['dist_bayesfactor_uncorrected']
+		res['__cli_changed_rows'] = np.flatnonzero(delta != 0)
+		res['__cli_correction'] = delta[delta != 0]
+		assert (delta >= 0).all()
+	else:
+		res['dist_bayesfactor_uncorrected'] = res['dist_bayesfactor'].copy()
+	# the 'dist_bayesfactor' column is the float32 copy taken BEFORE the correction (fits_standin header)
+	assert (native(out['dist_bayesfactor']) == res['dist_bayesfactor_uncorrected'].astype(np.float32)).all()
+	if 'dist_bayesfactor_corrected' in out.dtype.names:
+		assert (native(out['dist_bayesfactor_corrected']) == res['dist_bayesfactor'].astype(np.float32)).all()
+	# without magnitude columns p_single IS dist_post (total == log_bf, nway.py:526-527); float64 in the script's ``post``
+	res['p_single'] = np.array(g['post'], dtype=float)
+	if not g['biases']:
+		res['dist_post'] = res['p_single'].copy()
+		assert (native(out['dist_post']) == res['dist_post'].astype(np.float32)).all()
+	else:
+		res['dist_post'] = native(out['dist_post'])
+	res['prob_has_match'] = np.array(g['prob_has_match'], dtype=float)
+	res['prob_this_match'] = np.array(g['prob_this_match'], dtype=float)
+	for c in ('p_single', 'prob_has_match', 'prob_this_match'):
+		col = {'p_single': 'p_single', 'prob_has_match': 'p_any', 'prob_this_match': 'p_i'}[c]
+		assert (native(out[col]) == res[c].astype(np.float32)).all(), c
+	for col in out.dtype.names:
+		if col.startswith('bias_'):
+			res[col] = native(out[col])
+	res['__seconds'] = np.array([g['__seconds__']])
+	return res
+
+
+def prefixed(res, prefix):
+	out = {}
+	for key, v in res.items():
+		if key.startswith('__cli_'):
+			out[prefix.replace('script_', '') + key[2:]] = v
+		elif key.startswith('__'):
+			continue
+		else:
+			out[prefix + key] = v
+	return out
+
+
+def cat(name, ra, dec, error, area):
+	return dict(name=name, ra=np.array(ra, dtype=float), dec=np.array(dec, dtype=float), error=np.array(error, dtype=float), area=float(area),
+		mags=[], maghists=[], magnames=[])
+
+
+def subset(res, step):
+	mask = (res['idx'][:, 0] % step) == 0
+	out = {}
+	for key, v in res.items():
+		if key.startswith('__'):
+			continue
+		out['sub_' + key] = v[mask]
+	out['sub_rows'] = np.flatnonzero(mask).astype(np.int64)
+	out['sub_step'] = np.array([step])
+	return out
+
+
+def checksums(res, k):
+	from goldenutil import idx_hash
+	out = {'idx_hash': np.array([idx_hash(res['idx'])], dtype=np.uint64), 'nrows': np.array([len(res['idx'])]),
+		'rows_per_primary': np.bincount(res['idx'][:, 0]).astype(np.int32),
+		'flag_counts': np.bincount(res['match_flag'], minlength=3), 'ncat_counts': np.bincount(res['ncat'], minlength=k + 1)}
+	for c in ('Separation_max', 'dist_bayesfactor_uncorrected', 'dist_bayesfactor', 'dist_post', 'p_single', 'prob_has_match', 'prob_this_match'):
+		out['sum_' + c] = np.array([np.sum(res[c], dtype=float)])
+	for i in range(k):
+		for j in range(i + 1, k):
+			out['sum_sep_%d_%d' % (i, j)] = np.array([np.nansum(res['sep_%d_%d' % (i, j)], dtype=float)])
+	return out
+
+
+def gen_api():
+	from goldenutil import ell_tables, xmm_tables, fuzz_cases, golden
+	out = {}
+	# edge.npz's 3-way tables with cells straddling Dec = 0, and their first two catalogues (was f32.npz)
+	e = golden('edge')
+	tabs = [cat('ABC'[i], e['neg_ra%d' % i], e['neg_dec%d' % i], e['neg_err%d' % i], float(e['neg_area'][0])) for i in range(3)]
+	radius = float(e['neg_radius'][0])
+	r3 = script_table(tabs, radius, e['neg_completeness'], tag='neg3')
+	out.update(prefixed(r3, 'neg_w3_script_'))
+	out.update(prefixed(script_table(tabs[:2], radius, e['neg_completeness'][:2], tag='neg2'), 'neg_w2_script_'))
+	print('neg: %d rows, %d corrected' % (len(r3['idx']), len(r3['__cli_changed_rows'])))
+	# the generic-k tables of kway.npz
+	g = golden('kway')
+	for tag, k in (('k4c', 4), ('k5', 5), ('k6', 6), ('k8', 8)):
+		names = ['T%d' % i for i in range(k)]
+		tabs = [cat(names[i], g['%s_ra%d' % (tag, i)], g['%s_dec%d' % (tag, i)], g['%s_err%d' % (tag, i)], g[tag + '_area'][0]) for i in range(k)]
+		comp = g[tag + '_completeness']
+		r = script_table(tabs, float(g[tag + '_radius'][0]), comp, tag=tag)
+		out.update(prefixed(r, tag + '_script_'))
+		print('%s: %d rows, %d corrected (sum %.6f), %.1f s' % (tag, len(r['idx']), len(r['__cli_changed_rows']), r['__cli_correction'].sum(), r['__seconds'][0]))
+	# kmulti.npz: 5- and 6-way with several sources per catalogue
+	from test_oracle_golden import kmulti_cases
+	for tag, names, tabs, radius, comp, _ in kmulti_cases():
+		r = script_table([cat(t['name'], t['ra'], t['dec'], t['error'], t['area']) for t in tabs], radius, comp, tag=tag)
+		out.update(prefixed(r, tag + '_script_'))
+		print('%s: %d rows, %d corrected, %.1f s' % (tag, len(r['idx']), len(r['__cli_changed_rows']), r['__seconds'][0]))
+	# the randomized configurations without magnitude columns
+	for tag, tabs, radius, comp, opts, fg in fuzz_cases():
+		if tag + 'empty' in fg.files or tabs[-1]['mags']:
+			continue
+		plain = [cat(t['name'], t['ra'], t['dec'], t['error'], t['area']) for t in tabs]
+		r = script_table(plain, radius, comp, ratio=opts['prob_ratio_secondary'], tag=tag)
+		out.update(prefixed(r, tag + 'script_'))
+	print('fuzz done')
+	# sparse fields, flat cells and the HEALPix branch
+	g = golden('sparse')
+	names = ['P', 'A', 'B', 'C']
+	for shift, where in ((0.0, 'flat'), (65.0, 'high')):
+		tabs = [cat(names[i], g['ra%d' % i], g['dec%d' % i] + shift, g['err%d' % i], 100.) for i in range(4)]
+		for k in (2, 3, 4):
+			tag = '%s%d_' % (where, k)
+			r = script_table(tabs[:k], 6., g['completeness'][:k], tag=tag)
+			out.update(prefixed(r, tag + 'script_'))
+			print('sparse %s: %d rows, %.1f s' % (tag, len(r['idx']), r['__seconds'][0]))
+	# both poles and the RA seam (the script's HEALPix branch over oracle/healpix.py)
+	g = golden('allsky')
+	tabs = [cat('ABC'[i], g['ra%d' % i], g['dec%d' % i], g['err%d' % i], g['area'][0]) for i in range(3)]
+	r = script_table(tabs, float(g['radius'][0]), float(g['completeness'][0]), tag='allsky3')
+	out.update(prefixed(r, 'allsky_w3_script_'))
+	out.update(prefixed(script_table(tabs[:2], float(g['radius'][0]), float(g['completeness'][0]), tag='allsky2'), 'allsky_w2_script_'))
+	print('allsky: %d rows, %d corrected, %.1f s' % (len(r['idx']), len(r['__cli_changed_rows']), r['__seconds'][0]))
+	# COSMOS_XMM x the seeded stand-ins, three catalogues
+	X, O, I = xmm_tables()
+	s = golden('xmm_syn')
+	comp = float(s['completeness'][0]) if 'completeness' in s.files else 0.9
+	r = script_table([X, O, I], 20., comp, tag='xmm3')
+	print('xmm3: %d rows, %d corrected, %.1f s' % (len(r['idx']), len(r['__cli_changed_rows']), r['__seconds'][0]))
+	out.update(prefixed({key: v for key, v in r.items() if key.startswith('__cli_')}, 'xmm_w3_script_'))
+	out.update({'xmm_w3_script_' + key: v for key, v in checksums(r, 3).items()})
+	out.update({'xmm_w3_script_' + key: v for key, v in subset(r, 12).items()})
+	# elltest, three catalogues
+	X, R, O = ell_tables()
+	r = script_table([X, R, O], 10., 1.0, tag='ell3')
+	print('ell3: %d rows, %d corrected, %.1f s' % (len(r['idx']), len(r['__cli_changed_rows']), r['__seconds'][0]))
+	out.update(prefixed({key: v for key, v in r.items() if key.startswith('__cli_')}, 'ell3_script_'))
+	out.update({'ell3_script_' + key: v for key, v in checksums(r, 3).items()})
+	out.update({'ell3_script_' + key: v for key, v in subset(r, 10).items()})
+	save('script_api', **out)
+
+
+# ---------------------------------------------------------------------------
+# command lines on FITS files
+
+def table_record(path, meta, arrays, tag, g, full=True, step=8):
+	"""what the script wrote: names / TFORMs / header keys into ``meta``; the computed columns (everything
+	that is not a copy of an input column, plus the ID columns) into ``arrays``"""
+	hdus = fits_standin.open(path)
+	t = hdus[1]
+	names = [c.name for c in t.columns]
+	inputs = set()
+	for table_name in hdus[0].header['TABLES'].split(', '):
+		inputs.update(n for n in names if n.startswith(table_name + '_'))
+	# header keys and COMMENT texts as the script handed them over (g['hdulist']: the file splits long ones over cards);
+	# read back from the file they must be the same
+	logical = g['hdulist'][0].header
+	primary = {key: v for key, v in logical.items() if key != 'DATE'}
+	assert all(hdus[0].header[key] == v for key, v in primary.items())
+	assert ''.join(hdus[0].header.comments).replace(' ', '') == ''.join(logical.comments).replace(' ', '')
+	meta[tag] = dict(columns=names, formats=[c.format for c in t.columns], extname=t.name, nrows=int(len(t.data)),
+		primary_header=primary, comments=list(logical.comments), has_date='DATE' in logical)
+	keep = [n for n in names if n not in inputs or n.endswith('_ID')]
+	data = t.data
+	if not full:
+		first = native(data[names[0]])
+		order = np.unique(first)
+		chosen = order[::step]
+		mask = np.isin(first, chosen)
+		arrays[tag + '/rows'] = np.flatnonzero(mask).astype(np.int64)
+		for n in keep:
+			col = native(data[n])
+			if col.dtype.kind == 'f':
+				arrays[tag + '/sum/' + n] = np.array([np.nansum(col, dtype=float)])
+		arrays[tag + '/all/match_flag'] = native(data['match_flag']).astype(np.int8)
+		arrays[tag + '/all/ncat'] = native(data['ncat']).astype(np.int8)
+		data = data[mask]
+	for n in keep:
+		arrays[tag + '/' + n] = native(data[n])
+	# the copies of the input columns: one of them in full (the -99 convention), the rest are gathers by ID
+	return hdus
+
+
+def mag3_catalogues():
+	from goldenutil import mag3_tables
+	X, O, I = mag3_tables()
+	shutil.copy(os.path.join(REFERENCE, 'doc', 'COSMOS_XMM.fits'), 'COSMOS_XMM.fits')
+	fits_standin.write_catalogue('OPT.fits', 'OPT', O['area'], [('ID', 'J', np.arange(len(O['ra']))), ('RA', 'D', O['ra']), ('DEC', 'D', O['dec']),
+		('R', 'D', O['mags'][0]), ('I', 'D', O['mags'][1])])
+	fits_standin.write_catalogue('IRAC.fits', 'IRAC', I['area'], [('ID', 'J', np.arange(len(I['ra']))), ('RA', 'D', I['ra']), ('DEC', 'D', I['dec']),
+		('CH1', 'D', I['mags'][0])])
+
+
+def gen_cli():
+	meta, arrays = {}, {}
+	for f in ('randomcatX.fits', 'randomcatR.fits', 'randomcatO.fits'):
+		shutil.copy(os.path.join(REFERENCE, 'tests', 'elltest', f), f)
+	X, R, O = 'randomcatX.fits', 'randomcatR.fits', 'randomcatO.fits'
+	cases = [
+		# the reference's own command (tests/elltest/genrandom_geometric.sh:14)
+		('ell2_minprob', ['--radius=10.0', X, ':pos_err', O, '0.1', '--out=ell2_minprob.fits', '--min-prob=0.01'], True),
+		('ell2', ['--radius', '10', X, ':pos_err', O, '0.1', '--out', 'ell2.fits', '--prior-completeness', '0.9'], True),
+		('ell3_minprob', ['--radius', '10', X, ':pos_err', R, ':pos_err', O, '0.1', '--out', 'ell3_minprob.fits', '--min-prob', '0.01'], True),
+		('ell3_ignore', ['--radius', '10', X, ':pos_err', R, ':pos_err', O, '0.1', '--out', 'ell3_ignore.fits', '--min-prob', '0.01',
+			'--ignore-unrelated-associations'], True),
+		('ell3_opts', ['--radius', '8', X, ':pos_err', R, '0.7', O, '0.1', '--out', 'ell3_opts.fits', '--min-prob', '0.005',
+			'--prior-completeness', '0.9:0.8', '--acceptable-prob', '0.3'], True),
+		('ell3', ['--radius', '10', X, ':pos_err', R, ':pos_err', O, '0.1', '--out', 'ell3.fits'], False),
+	]
+	for tag, argv, full in cases:
+		g, log = run_script(argv)
+		table_record(tag + '.fits', meta, arrays, tag, g, full=full, step=12)
+		meta[tag]['argv'] = argv
+		print('%-14s %7d rows  %.1f s' % (tag, meta[tag]['nrows'], g['__seconds__']))
+	# magnitude priors: COSMOS_XMM (the real file) x seeded OPT / IRAC stand-ins with magnitude columns
+	mag3_catalogues()
+	base = ['--radius', '20', 'COSMOS_XMM.fits', ':pos_err', 'OPT.fits', '0.1', 'IRAC.fits', '0.5', '--prior-completeness', '0.9']
+	auto = ['--mag', 'OPT:R', 'auto', '--mag', 'OPT:I', 'auto', '--mag', 'IRAC:CH1', 'auto']
+	for tag, extra in (('mag_post', auto), ('mag_rad', auto + ['--mag-radius', '3.3']),
+			('mag_rad_excl', auto + ['--mag-radius', '2.5', '--mag-exclude-radius', '6', '--min-prob', '0.02']),
+			('mag_minprob', auto + ['--mag-auto-minprob', '0.8', '--acceptable-prob', '0.2'])):
+		argv = base + extra + ['--out', tag + '.fits']
+		g, log = run_script(argv)
+		table_record(tag + '.fits', meta, arrays, tag, g, full=(tag in ('mag_post', 'mag_rad_excl')), step=5)
+		meta[tag]['argv'] = argv
+		meta[tag]['histogram_files'] = {}
+		for name in ('OPT_R_fit.txt', 'OPT_I_fit.txt', 'IRAC_CH1_fit.txt'):
+			meta[tag]['histogram_files'][name] = open(name).read()
+			shutil.copy(name, tag + '_' + name)
+		print('%-14s %7d rows  %.1f s' % (tag, meta[tag]['nrows'], g['__seconds__']))
+	# a histogram FILE instead of auto (the one the posterior run stored) for one column, auto for another
+	argv = base + ['--mag', 'OPT:R', 'mag_post_OPT_R_fit.txt', '--mag', 'IRAC:CH1', 'auto', '--out', 'mag_file.fits']
+	g, log = run_script(argv)
+	table_record('mag_file.fits', meta, arrays, 'mag_file', g, full=False, step=5)
+	meta['mag_file']['argv'] = argv
+	meta['mag_file']['histogram_files'] = {'IRAC_CH1_fit.txt': open('IRAC_CH1_fit.txt').read()}
+	print('%-14s %7d rows  %.1f s' % ('mag_file', meta['mag_file']['nrows'], g['__seconds__']))
+	save('script_cli', **arrays)
+	with open(os.path.join(HERE, 'script_cli.json'), 'w') as f:
+		json.dump(meta, f, indent=1, sort_keys=True)
+	# the reference's own test catalogues and its COSMOS_XMM.fits, byte for byte, for the product's command line
+	dest = os.path.join(HERE, 'elltest')
+	os.makedirs(dest, exist_ok=True)
+	for f in ('randomcatX.fits', 'randomcatR.fits', 'randomcatO.fits'):
+		shutil.copyfile(os.path.join(REFERENCE, 'tests', 'elltest', f), os.path.join(dest, f))
+	shutil.copyfile(os.path.join(REFERENCE, 'doc', 'COSMOS_XMM.fits'), os.path.join(dest, 'COSMOS_XMM.fits'))
+
+
+if __name__ == '__main__':
+	which = sys.argv[1:] or ['cli', 'api']
+	if 'cli' in which:
+		gen_cli()
+	if 'api' in which:
+		gen_api()
+	shutil.rmtree(SCRATCH, ignore_errors=True)

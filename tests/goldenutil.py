@@ -171,6 +171,29 @@ def atol_for(column, atol=ATOL):
 	return max(atol, ATOL_LOG) if (column in LOGCOLS and atol >= ATOL) else atol
 
 
+def script_golden():
+	"""tests/golden/script_api.npz: the reference's SCRIPT (nway.py, executed by make_script_golden.py) on the inputs of the API
+	fixtures -- what ``unrelated_associations='cli', f32_roundtrip=True`` has to reproduce"""
+	return golden('script_api')
+
+
+# a golden column the script only ever holds in float32 (its separations after the trip through the FITS 'E' columns) is stored
+# as float32: the value it is compared with may differ from it by the rounding of the STORED number, 6e-8 relative
+F32_STORED_RTOL = 1.5e-7
+
+
+def _rtol_for(golden_array, rtol):
+	return max(rtol, F32_STORED_RTOL) if golden_array.dtype == np.float32 else rtol
+
+
+def assert_script_correction(table, gs, prefix, rtol=RTOL):
+	"""rows changed by the script's unrelated-association loop (nway.py:366-420) and by how much: the difference of two runs of
+	the script (with and without --ignore-unrelated-associations), both in float64"""
+	delta = np.asarray(table['dist_bayesfactor']) - np.asarray(table['dist_bayesfactor_uncorrected'])
+	np.testing.assert_array_equal(np.flatnonzero(delta != 0), gs[prefix + 'cli_changed_rows'])
+	np.testing.assert_allclose(delta[delta != 0], gs[prefix + 'cli_correction'], rtol=rtol)
+
+
 def assert_table_matches(table, g, prefix, names, rows=None, rtol=RTOL, atol=ATOL, soak=False):
 	"""compare a result table (dict of arrays) with golden arrays stored under ``prefix``: the
 	contract of the north star, 1e-6 relative (1e-12 absolute) on every floating column.  ``soak``:
@@ -184,10 +207,12 @@ def assert_table_matches(table, g, prefix, names, rows=None, rtol=RTOL, atol=ATO
 	np.testing.assert_array_equal(sel(table['match_flag']), g[prefix + 'match_flag'])
 	for i in range(k):
 		for j in range(i + 1, k):
+			want = g[prefix + 'sep_%d_%d' % (i, j)]
 			np.testing.assert_allclose(sel(table['Separation_%s_%s' % (names[i], names[j])]),
-				g[prefix + 'sep_%d_%d' % (i, j)], rtol=rtol, atol=1e-9, equal_nan=True)
+				want.astype(float), rtol=_rtol_for(want, rtol), atol=1e-9, equal_nan=True)
 	for c in FLOATCOLS:
-		np.testing.assert_allclose(sel(table[c]), g[prefix + c], rtol=rtol, atol=(atol_for(c, atol) if soak else atol), err_msg=c)
+		want = g[prefix + c]
+		np.testing.assert_allclose(sel(table[c]), want.astype(float), rtol=_rtol_for(want, rtol), atol=(atol_for(c, atol) if soak else atol), err_msg=c)
 
 
 def assert_checksums_match(table, g, prefix, names, rtol=1e-9):
@@ -200,7 +225,7 @@ def assert_checksums_match(table, g, prefix, names, rtol=1e-9):
 	np.testing.assert_array_equal(np.bincount(table['match_flag'], minlength=3), g[prefix + 'flag_counts'])
 	np.testing.assert_array_equal(np.bincount(table['ncat'], minlength=k + 1), g[prefix + 'ncat_counts'])
 	for c in FLOATCOLS:
-		np.testing.assert_allclose(np.sum(table[c]), g[prefix + 'sum_' + c][0], rtol=rtol, err_msg=c)
+		np.testing.assert_allclose(np.sum(table[c], dtype=float), g[prefix + 'sum_' + c][0], rtol=rtol, err_msg=c)
 	for i in range(k):
 		for j in range(i + 1, k):
 			np.testing.assert_allclose(np.nansum(table['Separation_%s_%s' % (names[i], names[j])]),

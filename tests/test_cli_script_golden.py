@@ -1,0 +1,121 @@
+"""The product's command line (nway.py -> nway_amd/cli.py) against what the REFERENCE'S SCRIPT wrote.
+
+tests/golden/script_cli.{npz,json} were made by executing /root/reference/nway.py itself
+(tests/golden/make_script_golden.py, build container, an I/O-only stand-in for astropy.io.fits): for
+every command line below the table it wrote -- column names, order, TFORMs, every computed
+column as stored (float32 'E' / int16 'I'), the header keys of the primary HDU, the COMMENT
+cards, the ``*_fit.txt`` histogram files.  The product is given the same command line on the
+same files (the reference's own tests/elltest catalogues and doc/COSMOS_XMM.fits, byte for byte
+under tests/golden/elltest/) and has to write the same table: index and flag columns bit-equal,
+floating columns within 1e-6 relative of the float32 values (BASELINE.json's contract).
+"""
+import json
+import os
+import shutil
+
+import numpy as np
+import pytest
+
+from goldenutil import GOLDEN, golden, mag3_tables
+
+pytestmark = pytest.mark.gpu
+
+META = json.load(open(os.path.join(GOLDEN, 'script_cli.json')))
+ELL = ['ell2_minprob', 'ell2', 'ell3_minprob', 'ell3_ignore', 'ell3_opts', 'ell3']
+MAG = ['mag_post', 'mag_rad', 'mag_rad_excl', 'mag_minprob', 'mag_file']
+RTOL, ATOL = 1e-6, 1e-12
+
+
+def stage_inputs(tag, tmp_path):
+	from nway_amd import _fits
+	if tag in ELL:
+		for f in ('randomcatX.fits', 'randomcatR.fits', 'randomcatO.fits'):
+			shutil.copy(os.path.join(GOLDEN, 'elltest', f), str(tmp_path / f))
+		return
+	shutil.copy(os.path.join(GOLDEN, 'elltest', 'COSMOS_XMM.fits'), str(tmp_path / 'COSMOS_XMM.fits'))
+	X, O, I = mag3_tables()
+	_fits.write_table(str(tmp_path / 'OPT.fits'), [('ID', 'J', np.arange(len(O['ra']))), ('RA', 'D', O['ra']), ('DEC', 'D', O['dec']),
+		('R', 'D', O['mags'][0]), ('I', 'D', O['mags'][1])], 'OPT', table_header={'SKYAREA': O['area']})
+	_fits.write_table(str(tmp_path / 'IRAC.fits'), [('ID', 'J', np.arange(len(I['ra']))), ('RA', 'D', I['ra']), ('DEC', 'D', I['dec']),
+		('CH1', 'D', I['mags'][0])], 'IRAC', table_header={'SKYAREA': I['area']})
+	if tag == 'mag_file':
+		# the histogram the script stored in its posterior run, handed back as a file (nway.py:501-504)
+		with open(str(tmp_path / 'mag_post_OPT_R_fit.txt'), 'w') as f:
+			f.write(META['mag_post']['histogram_files']['OPT_R_fit.txt'])
+
+
+def compare_float(got, want, name):
+	got, want = np.asarray(got, dtype=float), np.asarray(want, dtype=float)
+	np.testing.assert_array_equal(np.isnan(got), np.isnan(want), err_msg=name)
+	np.testing.assert_allclose(got, want, rtol=RTOL, atol=ATOL, equal_nan=True, err_msg=name)
+
+
+def check_input_copies(out, tmp_path, meta):
+	"""every input column copied as {TABLE}_{column}, -99 where the catalogue has no source in the row (fastskymatch.py:265-282)"""
+	from nway_amd import _fits
+	for filename, table_name in zip(meta['primary_header']['INPUT'].split(', '), meta['primary_header']['TABLES'].split(', ')):
+		t = _fits.read_table(str(tmp_path / filename))
+		ids = np.asarray(t.data['ID'])
+		order = np.argsort(ids)
+		got_id = np.asarray(out.data[table_name + '_ID'])
+		present = got_id != -99
+		rows = order[np.searchsorted(ids[order], got_id[present])]
+		np.testing.assert_array_equal(ids[rows], got_id[present])
+		for col in t.data.dtype.names:
+			got = np.asarray(out.data['%s_%s' % (table_name, col)])
+			np.testing.assert_array_equal(got[present], np.asarray(t.data[col])[rows], err_msg=col)
+			np.testing.assert_array_equal(got[~present], -99, err_msg=col)
+
+
+@pytest.mark.parametrize('tag', ELL + MAG)
+def test_cli_writes_what_the_script_writes(tag, tmp_path, monkeypatch):
+	from nway_amd import _fits, cli
+	meta, g = META[tag], golden('script_cli')
+	monkeypatch.chdir(tmp_path)
+	stage_inputs(tag, tmp_path)
+	assert cli.main(list(meta['argv'])) == 0
+	outfile = tag + '.fits'
+	out = _fits.read_table(outfile)
+	# layout: names, order, storage types
+	assert out.name == meta['extname'] == 'NWAYMATCH'
+	assert out.names == meta['columns']
+	assert out.formats == meta['formats']
+	assert len(out.data) == meta['nrows']
+	# header of the primary HDU (nway.py:640-647, fastskymatch.py:287-290,353-354)
+	head = _fits.read_header(outfile, 0)
+	assert ('DATE' in head) == meta['has_date']
+	for key, want in meta['primary_header'].items():
+		if key == 'NWAYCMD':
+			assert head[key].split()[1:] == want.split()[1:]  # all but the path of the script itself
+		else:
+			assert head[key] == want, key
+	squeeze = lambda texts: ''.join(texts).replace(' ', '')
+	assert squeeze(head['_COMMENTS']) == squeeze(meta['comments'])
+	# the computed columns
+	inputs = set()
+	for table_name in meta['primary_header']['TABLES'].split(', '):
+		inputs.update(n for n in meta['columns'] if n.startswith(table_name + '_'))
+	computed = [n for n in meta['columns'] if n not in inputs or n.endswith('_ID')]
+	rows = g[tag + '/rows'] if (tag + '/rows') in g.files else slice(None)
+	for name in computed:
+		want = g['%s/%s' % (tag, name)]
+		got = np.asarray(out.data[name])[rows]
+		if want.dtype.kind in 'iu':
+			np.testing.assert_array_equal(got, want, err_msg=name)
+		else:
+			assert np.asarray(out.data[name]).dtype == np.float32
+			compare_float(got, want, name)
+	if (tag + '/rows') in g.files:
+		np.testing.assert_array_equal(out.data['match_flag'], g[tag + '/all/match_flag'])
+		np.testing.assert_array_equal(out.data['ncat'], g[tag + '/all/ncat'])
+		for name in computed:
+			key = '%s/sum/%s' % (tag, name)
+			if key in g.files:
+				np.testing.assert_allclose(np.nansum(np.asarray(out.data[name]), dtype=float), g[key][0], rtol=1e-6, err_msg=name)
+	check_input_copies(out, tmp_path, meta)
+	# the histograms the script stores next to its output (nway.py:491-497)
+	for name, text in meta.get('histogram_files', {}).items():
+		want = np.loadtxt(text.splitlines())
+		got = np.loadtxt(name)
+		assert open(name).readline() == text.splitlines(True)[0]
+		np.testing.assert_allclose(got, want, rtol=0, atol=1.001e-5, err_msg=name)
