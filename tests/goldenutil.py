@@ -186,12 +186,12 @@ def _rtol_for(golden_array, rtol):
 	return max(rtol, F32_STORED_RTOL) if golden_array.dtype == np.float32 else rtol
 
 
-def assert_script_correction(table, gs, prefix, rtol=RTOL):
+def assert_script_correction(table, gs, prefix, rtol=RTOL, atol=0.):
 	"""rows changed by the script's unrelated-association loop (nway.py:366-420) and by how much: the difference of two runs of
 	the script (with and without --ignore-unrelated-associations), both in float64"""
 	delta = np.asarray(table['dist_bayesfactor']) - np.asarray(table['dist_bayesfactor_uncorrected'])
 	np.testing.assert_array_equal(np.flatnonzero(delta != 0), gs[prefix + 'cli_changed_rows'])
-	np.testing.assert_allclose(delta[delta != 0], gs[prefix + 'cli_correction'], rtol=rtol)
+	np.testing.assert_allclose(delta[delta != 0], gs[prefix + 'cli_correction'], rtol=rtol, atol=atol)
 
 
 def assert_table_matches(table, g, prefix, names, rows=None, rtol=RTOL, atol=ATOL, soak=False):

@@ -112,7 +112,7 @@ def test_ell3():
 	# the same loop on float64 separations (the product's unrelated_associations='cli' without f32_roundtrip) is run by no
 	# reference code; it follows the script's to within the float32 rounding of the separations
 	tc = orc.nway_match([X, R, O], 10., 1.0, correction='cli')
-	assert_script_correction(tc, gs, 'ell3_', rtol=5e-6)
+	assert_script_correction(tc, gs, 'ell3_', rtol=5e-6, atol=2e-6)
 
 
 def test_xmm_standins():
@@ -177,7 +177,7 @@ def test_four_and_five_way_with_script_correction():
 		assert_table_matches(t, g, tag + '_', names, **TIGHT)
 		gs = script_golden()
 		tc = orc.nway_match(tabs, float(g[tag + '_radius'][0]), comp, correction='cli')
-		assert_script_correction(tc, gs, tag + '_', rtol=5e-6)  # float64 separations: no reference run has them (see the elltest case)
+		assert_script_correction(tc, gs, tag + '_', rtol=5e-6, atol=2e-6)  # float64 separations: no reference run has them (see the elltest case)
 		tcc = orc_c.nway_match(tabs, float(g[tag + '_radius'][0]), comp, correction='cli')
 		np.testing.assert_allclose(tcc['dist_bayesfactor'], tc['dist_bayesfactor'], rtol=1e-12)
 		np.testing.assert_array_equal(tcc['match_flag'], tc['match_flag'])
