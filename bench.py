@@ -261,7 +261,7 @@ def live_traffic(argv_tail, n_secondary, budget_s=150.0):
 	import tempfile
 	prof = shutil.which('rocprofv3') or ('/opt/rocm/bin/rocprofv3' if os.path.exists('/opt/rocm/bin/rocprofv3') else None)
 	if prof is None:
-		return None, 'rocprofv3 not found'
+		return None, 'rocprofv3 not found', None
 	out = tempfile.mkdtemp(prefix='nway_bench_pmc_')
 	t0 = time.perf_counter()
 	vals = {}
@@ -269,7 +269,7 @@ def live_traffic(argv_tail, n_secondary, budget_s=150.0):
 		for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
 			left = budget_s - (time.perf_counter() - t0)
 			if left < 20:
-				return None, 'time budget of the counter passes spent'
+				return None, 'time budget of the counter passes spent', None
 			cmd = [prof, '--pmc', counter, '--output-format', 'csv', '-d', os.path.join(out, counter), '--', sys.executable, os.path.abspath(__file__),
 				'--steps', '6', '--warmup', '2', '--prewarm', '20', '--cpu-sample', '0', '--two-pipelines', '0', '--live-traffic', '0'] + argv_tail
 			env = dict(os.environ, TMPDIR='/tmp')
@@ -284,27 +284,31 @@ def live_traffic(argv_tail, n_secondary, budget_s=150.0):
 				except OSError:
 					pass
 				proc.communicate()
-				return None, 'rocprofv3 --pmc %s did not finish in %.0f s' % (counter, left)
+				return None, 'rocprofv3 --pmc %s did not finish in %.0f s' % (counter, left), None
 			files = glob.glob(os.path.join(out, counter, '*', '*counter_collection.csv'))
 			if proc.returncode != 0 or not files:
-				return None, 'rocprofv3 --pmc %s failed (rc %d): %s' % (counter, proc.returncode, stdout[-200:].replace('\n', ' '))
+				return None, 'rocprofv3 --pmc %s failed (rc %d): %s' % (counter, proc.returncode, stdout[-200:].replace('\n', ' ')), None
 			per = []
 			for r in csv.DictReader(open(files[0])):
 				if 'k_sweep' in r['Kernel_Name'] and r['Counter_Name'] == counter:
 					per.append(float(r['Counter_Value']))
 			if not per:
-				return None, 'no k_sweep dispatch in the %s pass' % counter
+				return None, 'no k_sweep dispatch in the %s pass' % counter, None
 			vals[counter] = sum(per) / len(per)
 	except Exception as e:
-		return None, '%s: %s' % (type(e).__name__, e)
+		return None, '%s: %s' % (type(e).__name__, e), None
 	finally:
 		shutil.rmtree(out, ignore_errors=True)
 	raw = vals['FETCH_SIZE'] * 1024
 	stream = 16.0 * n_secondary
 	fetch = raw + stream / 2 if raw >= stream / 2 else 2 * raw
-	return fetch + vals['WRITE_SIZE'] * 1024, ('measured in this run: child processes of this script under rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE '
-		'(separate passes), mean per k_sweep dispatch: FETCH %.0f KiB raw + the uncounted half of the 16 B/lane stream (gfx950), WRITE %.0f KiB; %.0f s'
-		% (vals['FETCH_SIZE'], vals['WRITE_SIZE'], time.perf_counter() - t0))
+	detail = dict(fetch_raw_bytes=raw, write_raw_bytes=vals['WRITE_SIZE'] * 1024, counters_raw_bytes=raw + vals['WRITE_SIZE'] * 1024,
+		correction_model_bytes=fetch - raw,
+		correction_note='MODEL, not a counter: gfx950 reports half of a wide (16 B per lane) coalesced streaming read (MI355X_MICROARCH.md, HBM/rocprofv3 '
+			'section); the uncounted half of the 16 B x n_secondary stream is added to the raw FETCH_SIZE (the gathers are counted in full)')
+	return fetch + vals['WRITE_SIZE'] * 1024, ('counters measured in this run (child processes of this script under rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, '
+		'separate passes, mean per k_sweep dispatch: FETCH %.0f KiB raw, WRITE %.0f KiB) + the guide\'s gfx950 correction, a model (traffic_detail); %.0f s'
+		% (vals['FETCH_SIZE'], vals['WRITE_SIZE'], time.perf_counter() - t0)), detail
 
 
 def job_bytes(sizes, error_columns, rows):
@@ -442,7 +446,7 @@ def main():
 	ap.add_argument('--scaling', choices=['weak', 'strong'], default='weak')
 	ap.add_argument('--sec-buffers', type=int, default=3, help='distinct device copies of the secondary catalogue the steps alternate over')
 	ap.add_argument('--cpu-sample', type=int, default=1000000, help='secondaries in the numpy leg of the CPU baseline (0 = no CPU baseline at all)')
-	ap.add_argument('--event-every', type=int, default=8, help='every n-th sweep launch of the timed region carries a HIP event pair')
+	ap.add_argument('--event-every', type=int, default=0, help='every n-th sweep launch of the timed region carries a HIP event pair (0 = choose: 2 for --steps <= 24, so that a short run still has >= 10 timed launches; 8 otherwise)')
 	ap.add_argument('--profile-stages', action='store_true', help='also time every stage (adds event records to the region)')
 	ap.add_argument('--prewarm', type=int, default=200, help='untimed steps before the W warm-up steps: the first ~10 ms after an idle period run at lower clocks (20 steps right after start-up: 82 us each, after 200: 78.5)')
 	ap.add_argument('--two-pipelines', type=int, default=1, help='also time the steps alternating over two (or this many, if > 2) independent pipelines (reported beside, never as, `value`); 0 = skip')
@@ -611,8 +615,9 @@ def main():
 	for _ in range(max(args.prewarm, 0) + args.warmup):
 		step()
 	mask = (1 << _hip.STAGES) - 1 if args.profile_stages else (1 << 1)
+	event_every = args.event_every if args.event_every > 0 else (2 if args.steps <= 24 else 8)
 	for pl in plans:
-		pl.profile(mask, 1 if args.profile_stages else max(args.event_every, 1))
+		pl.profile(mask, 1 if args.profile_stages else event_every)
 	barrier()
 	t0 = time.perf_counter()
 	for _ in range(args.steps):
@@ -624,7 +629,9 @@ def main():
 	elapsed = time.perf_counter() - t0
 	barrier()
 	launches, ms = [0] * _hip.STAGES, [0.0] * _hip.STAGES
+	sweep_samples = []
 	for pl in plans:
+		sweep_samples += pl.profile_samples(1)
 		n_, ms_ = pl.profile_read()
 		launches = [a + b for a, b in zip(launches, n_)]
 		ms = [a + b for a, b in zip(ms, ms_)]
@@ -643,13 +650,13 @@ def main():
 		sweep_ms = ms[1] / max(launches[1], 1)
 		alg_bytes = 16.0 * n_sec_swept
 		achieved = alg_bytes / (sweep_ms * 1e-3) / 1e9 if sweep_ms > 0 else 0.0
-		traffic, traffic_source = None, None
+		traffic, traffic_source, traffic_detail = None, None, None
 		live_note = None
 		under_profiler = any(k.startswith(('ROCPROF', 'ROCP_', 'ROCTX')) for k in os.environ)  # (a run that is itself being profiled does not start profilers)
 		if args.live_traffic and engine is None and world == 1 and args.cpu_sample != 0 and not under_profiler:
 			tail = ['--n-primary', str(args.n_primary), '--n-secondary', str(args.n_secondary), '--radius', str(args.radius), '--completeness', str(args.completeness),
 				'--seed', str(args.seed), '--sec-buffers', str(args.sec_buffers)]
-			traffic, traffic_source = live_traffic(tail, n_sec_swept)
+			traffic, traffic_source, traffic_detail = live_traffic(tail, n_sec_swept)
 			if traffic is None:
 				live_note, traffic_source = traffic_source, None
 		tf = os.path.join(ROOT, 'profiles', 'sweep_traffic.json')
@@ -693,8 +700,10 @@ def main():
 				setup_exchange=(None if engine is None else dict(seconds=engine.setup_seconds, bytes=engine.gathered_bytes,
 					note='one-time exchange at set-up (RCCL), outside the timed steps'))),
 			roofline=dict(bound='hbm', kernel='k_sweep', achieved=achieved, peak=HBM_PEAK_GBS, unit='GB/s',
-				frac=achieved / HBM_PEAK_GBS, traffic=traffic, traffic_source=traffic_source, algorithmic_bytes_per_launch=alg_bytes,
-				launch_ms=sweep_ms, launches_timed=int(launches[1]),
+				frac=achieved / HBM_PEAK_GBS, traffic=traffic, traffic_source=traffic_source, traffic_detail=traffic_detail, algorithmic_bytes_per_launch=alg_bytes,
+				launch_ms=sweep_ms, launches_timed=int(launches[1]), event_every=(1 if args.profile_stages else event_every),
+				launch_ms_min=(min(sweep_samples) if sweep_samples else None), launch_ms_median=(float(np.median(sweep_samples)) if sweep_samples else None),
+				launch_ms_max=(max(sweep_samples) if sweep_samples else None),
 				pass_bytes=p_bytes, pass_achieved=p_bytes / (ms_per_step * 1e-3) / 1e9, pass_frac=p_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
 				pass_note='SURVEY 8(d): every input column once + 66 B per row, divided by the WHOLE step (all launches and the gaps between them); rank 0'))
 		if io is not None:

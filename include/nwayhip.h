@@ -310,6 +310,10 @@ int nwayhip_comm_exchange(nwayhip_comm* comm, const void* d_export, void* d_impo
 #define NWAYHIP_PROFILE_RING 512
 int nwayhip_plan_profile(nwayhip_plan* plan, uint32_t stage_mask);
 int nwayhip_plan_profile_read(nwayhip_plan* plan, int64_t* h_launches /*[NWAYHIP_STAGES]*/, double* h_ms /*[NWAYHIP_STAGES]*/);
+/* The individual durations (ms) of the bracketed launch groups of one stage recorded so far, at most `capacity` of them
+ * (bench.py: minimum / median / maximum of the sweep's launches); waits for their events, resets nothing -- call it before
+ * nwayhip_plan_profile_read. */
+int nwayhip_plan_profile_samples(nwayhip_plan* plan, int32_t stage, double* h_ms /*[capacity]*/, int64_t capacity, int64_t* h_count);
 /* An event pair on a dispatch costs the pipeline a few microseconds on this stack: with `every` > 1
  * only every `every`-th launch of a single-launch stage (the sweep) carries one.  Default 1. */
 int nwayhip_plan_profile_stride(nwayhip_plan* plan, int32_t every);

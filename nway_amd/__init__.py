@@ -20,7 +20,7 @@ from ._hip import NwayHipError
 from .logger import NormalLogger, NullOutputLogger
 
 __version__ = '4.7.1'
-__hip_backend__ = 'libnwayhip/gfx950 ABI %d' % 1
+__hip_backend__ = 'libnwayhip/gfx950 ABI %d' % _hip.ABI_VERSION
 
 
 class UndersampledException(Exception):
@@ -123,6 +123,7 @@ class MatchResult(object):
 		self.nrows = int(status[_hip.ST_ROWS])
 
 	def column(self, name, index=None):
+		self.plan.check_live()
 		col = self.plan.cols[name]
 		if index is not None:
 			col = col[index]

@@ -103,6 +103,7 @@ SYMBOLS = {
 	'nwayhip_plan_profile': (ctypes.c_int, [_vp, ctypes.c_uint32]),
 	'nwayhip_plan_profile_read': (ctypes.c_int, [_vp, ctypes.POINTER(_i64), ctypes.POINTER(_dbl)]),
 	'nwayhip_plan_profile_stride': (ctypes.c_int, [_vp, _i32]),
+	'nwayhip_plan_profile_samples': (ctypes.c_int, [_vp, _i32, ctypes.POINTER(_dbl), _i64, ctypes.POINTER(_i64)]),
 	'nwayhip_group_stats': (ctypes.c_int, [_i64, _i64, _vp, _vp, _vp, _dbl, _vp, _vp, _vp, _vp, _vp]),
 	'nwayhip_bias_lookup': (ctypes.c_int, [_i64, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp]),
 	'nwayhip_catalogue_extent': (ctypes.c_int, [_vp, _vp, _i64, _vp, _vp]),
@@ -559,6 +560,14 @@ class MatchPlan(object):
 		check(self.lib.nwayhip_plan_profile_stride(self.handle, every))
 		check(self.lib.nwayhip_plan_profile(self.handle, stage_mask))
 
+	def profile_samples(self, stage):
+		"""the individual durations (ms) of the bracketed launches of one stage recorded so far (before profile_read resets them)"""
+		cap = 512
+		ms = (ctypes.c_double * cap)()
+		n = ctypes.c_int64(0)
+		check(self.lib.nwayhip_plan_profile_samples(self.handle, stage, ms, cap, ctypes.byref(n)))
+		return list(ms[:n.value])
+
 	def profile_read(self):
 		"""(launch groups, summed ms) per stage since the last call; waits for the events"""
 		n = (ctypes.c_int64 * STAGES)()
@@ -577,6 +586,7 @@ class MatchPlan(object):
 		are packed on the device -- one strided copy per type -- and come down into one page-locked buffer, of which the
 		returned arrays are views (no copy on the host; the buffer lives as long as one of them does and goes back to
 		torch's pinned-memory cache afterwards).  Returns (idx list, (ncat, match_flag) or None, list of float columns)."""
+		self.check_live()
 		t = torch()
 		n = int(nrows)
 		ni = self.ncat if with_idx else 0
@@ -615,8 +625,18 @@ class MatchPlan(object):
 
 	def release(self):
 		"""the caller is done with the table: the plan (workspace, table, staging) stays for the next match of the same shape
-		(plan cache below), or is closed"""
+		(plan cache below), or is closed.  Its columns are no longer the caller's: the next match of that shape overwrites them, so
+		a MatchResult of a released plan refuses to hand them out (``check_live``).  The cache holds at most PLAN_CACHE_ENTRIES plans
+		and PLAN_CACHE_BYTES of device memory that torch.cuda.empty_cache() cannot return: ``plan_cache_clear()`` frees it,
+		NWAY_PLAN_CACHE=0 in the environment turns the cache off.  Plans run on the stream that is current when they are
+		enqueued; a cached plan handed to another stream is ordered after its previous use only through the synchronisation
+		that read its status (every run_plan ends in one)."""
+		self.released = True
 		_plan_cache_put(self)
+
+	def check_live(self):
+		if getattr(self, 'released', False) or getattr(self, 'handle', None) is None:
+			raise NwayHipError('this match table was released (or its plan closed): its device columns belong to the next match of the same shape')
 
 	def __del__(self):
 		try:
@@ -683,6 +703,7 @@ def _plan_cache_get(key):
 		for i, (k, plan) in enumerate(_plan_cache):
 			if k == key:
 				del _plan_cache[i]
+				plan.released = False
 				return plan
 	return None
 
@@ -731,9 +752,11 @@ def run_plan(sizes, params, catalogues, cap_pairs, cap_rows, device, max_retries
 	tries = dict(table=0, path=0, pairs=0, rows=0, slots=0)
 	attempts = 0
 	request = _plan_key(sizes, params, cap_pairs, cap_rows, device, lean)
-	known = _plan_settled.get(request)
+	params = type(params).from_buffer_copy(params)  # the caller's struct is left as it was handed over; plan.params = what was settled on
+	with _plan_lock:
+		known = _plan_settled.get(request)
 	if known is not None:  # what this very request ended up with the last time
-		ctypes.memmove(ctypes.addressof(params), known[0], ctypes.sizeof(params))
+		params = type(params).from_buffer_copy(known[0])
 		cap_pairs, cap_rows = known[1], known[2]
 	while True:
 		plan = _new_plan(sizes, params, cap_pairs, cap_rows, device, lean)
@@ -745,8 +768,10 @@ def run_plan(sizes, params, catalogues, cap_pairs, cap_rows, device, max_retries
 		if os.environ.get('NWAYHIP_TRACE'):
 			sys.stderr.write('run_plan: link_slots %d flags %d rows %d cap_pairs %d cap_rows %d\n' % (plan.link_slots, flags, int(st[ST_ROWS]), cap_pairs, cap_rows))
 		if flags == 0:
-			if attempts > 1 and len(_plan_settled) < 64:
-				_plan_settled[request] = (bytes(params), int(cap_pairs), int(cap_rows))
+			if attempts > 1:
+				with _plan_lock:
+					if len(_plan_settled) < 64:
+						_plan_settled[request] = (bytes(params), int(cap_pairs), int(cap_rows))
 			return plan, st
 		sparse = plan.sparse
 		fused = plan.fused

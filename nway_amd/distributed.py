@@ -319,13 +319,15 @@ class SecondarySplitMatch(object):
 	that owns the primary -- contiguous row ranges, so the rank-order concatenation of the tables is
 	the global table.  One all-to-all of fixed-size export buffers per step (RCCL over xGMI; a few
 	hundred KB per peer) is the only collective; the owner turns what arrives into links and runs the
-	fused tail on its own primaries.  Needs the sparse path (few chance neighbours per primary): dense
-	fields shard by primary rows alone (``ShardedMatch``), where every GPU has enough work per row.
+	fused tail on its own primaries.  Needs the sparse path with its one-launch fused tail: few chance neighbours per
+	primary, AND at most four catalogues (three with the script's unrelated-association correction) -- five or more take the
+	hybrid path (csrc/plan.inc: TAILK_MAX_K), which this mode does not drive.  Everything else shards by primary rows
+	(``ShardedMatch``) or by declination zones (``ZoneShardedMatch``).
 
 	primary: this rank's shard of the primary catalogue (the shards are all-gathered once at set-up)
 	secondaries: list of this rank's SLICES of the secondary catalogues (``error`` may be a scalar)
 	capacity: records per (destination, catalogue) block of the export buffer (None: a first guess from the sizes, then
-	  what the settling step counted in the fullest block of any rank + 25 %: the exchange ships whole blocks)
+	  what the settling step counted in the fullest block of any rank, doubled: the exchange ships whole blocks)
 	tuning: development / test knobs of the plan (``_hip.make_params``), normally None
 
 	As in ``ShardedMatch`` the exchange logic only touches the hooks ``_exchange_device``, ``_sync``,
@@ -447,8 +449,10 @@ class SecondarySplitMatch(object):
 			if not self.plan.split_capable:
 				# (decided from the plan alone, the same on every rank: nothing has been allocated or exchanged yet)
 				self._drop_plan()
-				raise _hip.NwayHipError('the secondary-split mode needs the sparse path with its one-launch fused tail (few chance '
-					'neighbours per primary); shard dense fields by primary rows (ShardedMatch)')
+				raise _hip.NwayHipError('the secondary-split mode needs the sparse path with its one-launch fused tail: few chance '
+					'neighbours per primary and at most 4 catalogues (3 with the unrelated-association correction); this plan is '
+					'%d-way on path "%s". Shard by primary rows (ShardedMatch) or by declination zones (ZoneShardedMatch) instead'
+					% (int(self.params.ncat), self.plan.description.get('tail', '?') if hasattr(self.plan, 'description') else '?'))
 			nbytes = self.plan.split_buffer_bytes(self.world, capacity)
 			self.export = torch.zeros(nbytes, dtype=torch.uint8, device=self.device)
 			self.imported = torch.zeros(nbytes, dtype=torch.uint8, device=self.device)
@@ -479,10 +483,11 @@ class SecondarySplitMatch(object):
 				flags_any, slot_need = flags, int(st[_hip.ST_SLOT_NEED])
 			if flags_any == 0:
 				# the exchange ships whole blocks: size them by what this settling step counted -- the fullest block of any
-				# rank, a quarter more -- instead of the a-priori guess (5e5 x 1e8 over 8 ranks: 1 MB per peer for 0.2 MB of
-				# records).  A later step that outgrows it is flagged (PAIR_OVERFLOW: the receiver sees count > capacity).
+				# rank, twice that -- instead of the a-priori guess (5e5 x 1e8 over 8 ranks: 1 MB per peer for 0.2 MB of
+				# records).  A later step on OTHER catalogues that outgrows it is flagged (PAIR_OVERFLOW: the receiver sees
+				# count > capacity); ``resettle()`` then sizes the blocks again.
 				used = self._fullest_block()
-				tight = used + (used >> 2) + 64
+				tight = 2 * used + 64
 				if not tightened and self.capacity_fixed is None and tight * 3 < capacity * 2:
 					tightened = True
 					capacity = tight
@@ -553,6 +558,13 @@ class SecondarySplitMatch(object):
 		self.plan.split_front(self.cats, self.split)
 		self._exchange()
 		self.plan.split_back(self.cats, self.split)
+
+	def resettle(self):
+		"""COLLECTIVE: size the export blocks, the slots and the row capacity again (the settling loop of the set-up).  For a
+		caller whose ``step()`` came back with FLAG_PAIR_OVERFLOW / FLAG_ROW_OVERFLOW in ``read_status()`` after the slices
+		changed under the plan; every rank must call it."""
+		self._drop_plan()
+		self._build_plan()
 
 	def read_status(self):
 		if self.plan is None:
@@ -671,7 +683,11 @@ class ZoneShardedMatch(object):
 			prob_ratio_secondary=0.5, tuning=None, comm=None):
 		if isinstance(secondaries, dict):
 			secondaries = [secondaries]
-		self.comm = None  # (the set-up exchange is an all-to-all-v of rows through torch.distributed; nothing travels per step)
+		if comm not in (None, 'torch'):
+			# the set-up exchange is an all-to-all-v of rows through torch.distributed and nothing travels per step: there is
+			# no carrier to choose (the other two modes take comm='rccl')
+			raise ValueError("ZoneShardedMatch has no per-step exchange: comm must be None (got %r)" % (comm,))
+		self.comm = None
 		self.primary = primary
 		self.secondary_slices = secondaries
 		self.match_radius = float(match_radius)

@@ -138,7 +138,7 @@ def test_bench_live_traffic_degrades_gracefully(monkeypatch, tmp_path):
 	# (a) no rocprofv3 at all
 	monkeypatch.setattr('shutil.which', lambda name: None)
 	monkeypatch.setattr('os.path.exists', lambda p, _real=os.path.exists: False if p == '/opt/rocm/bin/rocprofv3' else _real(p))
-	traffic, why = bench.live_traffic([], 1000)
+	traffic, why, detail = bench.live_traffic([], 1000)
 	assert traffic is None and 'not found' in why
 	monkeypatch.undo()
 	# (b) a profiler that runs and fails (stand-in script): the reason is reported
@@ -146,17 +146,19 @@ def test_bench_live_traffic_degrades_gracefully(monkeypatch, tmp_path):
 	fake.write_text('#!/bin/sh\necho no device >&2\nexit 7\n')
 	fake.chmod(0o755)
 	monkeypatch.setattr('shutil.which', lambda name: str(fake))
-	traffic, why = bench.live_traffic([], 1000, budget_s=30.0)
+	traffic, why, detail = bench.live_traffic([], 1000, budget_s=30.0)
 	assert traffic is None and 'rc 7' in why
 	# (c) a profiler whose passes report 100 000 KiB fetched and 5 000 KiB written per k_sweep dispatch: the guide's correction
 	fake.write_text('#!/bin/sh\nwhile [ "$1" != "--pmc" ]; do shift; done; c=$2; while [ "$1" != "-d" ]; do shift; done; d=$2\n'
 		'mkdir -p $d/host; v=100000; [ "$c" = WRITE_SIZE ] && v=5000\n'
 		"printf '\"Kernel_Name\",\"Counter_Name\",\"Counter_Value\"\\n\"void k_sweep<1, true, true>(SweepArgs)\",\"%s\",%s\\n\"k_tail2(Tail2Args)\",\"%s\",1\\n' $c $v $c > $d/host/1_counter_collection.csv\n")
-	traffic, why = bench.live_traffic([], 10000000, budget_s=30.0)
-	assert traffic == 100000 * 1024 + 80e6 + 5000 * 1024 and why.startswith('measured in this run'), why
+	traffic, why, detail = bench.live_traffic([], 10000000, budget_s=30.0)
+	assert traffic == 100000 * 1024 + 80e6 + 5000 * 1024 and why.startswith('counters measured in this run'), why
+	# ... and the two parts apart: what the counters said, what the model adds
+	assert detail['counters_raw_bytes'] == 100000 * 1024 + 5000 * 1024 and detail['correction_model_bytes'] == 80e6 and 'MODEL' in detail['correction_note']
 	# (d) a pass that hangs: killed with its process group when the budget is spent
 	fake.write_text('#!/bin/sh\nsleep 300 &\nwait\n')
 	import time
 	t0 = time.time()
-	traffic, why = bench.live_traffic([], 1000, budget_s=22.0)
+	traffic, why, detail = bench.live_traffic([], 1000, budget_s=22.0)
 	assert traffic is None and 'did not finish' in why and time.time() - t0 < 40

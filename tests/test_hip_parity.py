@@ -68,6 +68,19 @@ def test_dist_log_bf_posterior_known_answers(nw):
 	assert bd.posterior(1e-3, 2.5) == pytest.approx(0.24043574366935122, rel=1e-12)
 
 
+def test_dist_of_absurd_coordinates_is_numpy_s(nw):
+	"""the public array function has a value for every finite argument, like the reference's numpy (fastskymatch.py:26-47):
+	coordinates a million turns off the sky go through the device library's full-range sincos (the kernels of the match
+	stop at 1.6e6 rad and give NaN = no match there, csrc/fastmath.inc: nw_sincos)"""
+	a = (np.array([1e9, -3.3e8, 10.0, 2e12]), np.array([1e8 + 0.25, 20.0, -5e9, 45.0]))
+	b = (np.array([1e9 + 0.001, -3.3e8 + 0.01, 10.0, 2e12]), np.array([1e8 + 0.2501, 20.0, -5e9 + 0.002, 45.001]))
+	got = nw.match.dist(a, b)
+	want = orc.dist(a, b)
+	assert np.isfinite(got).all() and np.isfinite(want).all()
+	# (the arguments themselves carry an ulp of 1e-7 degrees at 1e9; what is compared is the evaluation, to ~1e-9 of a degree)
+	np.testing.assert_allclose(got, want, rtol=1e-6, atol=1e-9)
+
+
 def test_dist_keeps_float32_like_numpy(nw):
 	"""fastskymatch.py:32-47 on float32 arrays stays float32 in numpy: so does dist() here
 	(k_dist_f32, same operation order); compared with the numpy oracle evaluated in float32 -- the two
