@@ -7,6 +7,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <dlfcn.h>
 
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
@@ -62,7 +63,29 @@ static void run(const char* what, dbl2* const* a, dbl2* const* b, long long nvec
 	printf("%-64s %4d workgroups of %4d  %7.2f us  %6.3f TB/s\n", what, blocks, THREADS, us, 32.0 * nvec / us * 1e-6);
 }
 
-int main() {
+// the library's own probe (elementwise.inc: k_read_probe) on THIS program's buffers, timed like the kernels above
+static void run_library(const char* path, dbl2* const* a, dbl2* const* b, long long nvec, int blocks, double* out) {
+	void* h = dlopen(path, RTLD_NOW);
+	if (!h) { printf("dlopen %s: %s\n", path, dlerror()); return; }
+	typedef int (*probe_fn)(const double*, const double*, long long, double*, int, void*);
+	probe_fn f = (probe_fn)dlsym(h, "nwayhip_read_probe");
+	hipEvent_t e0, e1;
+	CHECK(hipEventCreate(&e0));
+	CHECK(hipEventCreate(&e1));
+	for (int i = 0; i < 3; ++i) f((const double*)a[i], (const double*)b[i], 2 * nvec, out, blocks, nullptr);
+	CHECK(hipDeviceSynchronize());
+	const int reps = 12;
+	CHECK(hipEventRecord(e0));
+	for (int i = 0; i < reps; ++i) f((const double*)a[i % 3], (const double*)b[i % 3], 2 * nvec, out, blocks, nullptr);
+	CHECK(hipEventRecord(e1));
+	CHECK(hipEventSynchronize(e1));
+	float ms = 0;
+	CHECK(hipEventElapsedTime(&ms, e0, e1));
+	const double us = ms * 1e3 / reps;
+	printf("%-64s %4d workgroups of %4d  %7.2f us  %6.3f TB/s\n", "libnwayhip.so: nwayhip_read_probe (nontemporal)", blocks, 1024, us, 32.0 * nvec / us * 1e-6);
+}
+
+int main(int argc, char** argv) {
 	const long long nvec = 5000000;  // 2 x 80 MB
 	dbl2 *a[3], *b[3];
 	for (int i = 0; i < 3; ++i) {
@@ -75,6 +98,8 @@ int main() {
 	CHECK(hipMalloc(&out, 4096 * 8));
 	run<1024, 0, 2, false>("contiguous slices, 2 tiles in flight (the sweep, k_read_probe)", a, b, nvec, 256, out);
 	run<1024, 0, 2, true>("contiguous slices, 2 tiles, nontemporal", a, b, nvec, 256, out);
+	if (argc > 1) run_library(argv[1], a, b, nvec, 256, out);
+	run<1024, 0, 2, true>("contiguous slices, 2 tiles, nontemporal (again)", a, b, nvec, 256, out);
 	run<1024, 0, 4, false>("contiguous slices, 4 tiles in flight", a, b, nvec, 256, out);
 	run<1024, 0, 1, false>("contiguous slices, 1 tile in flight", a, b, nvec, 256, out);
 	run<1024, 1, 2, false>("tiles round robin over the workgroups, 2 in flight", a, b, nvec, 256, out);
