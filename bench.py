@@ -433,6 +433,88 @@ def extra_configs(args, world, rank, device, dist, backend):
 	return records
 
 
+FIXED_JOBS = [('c3s', [1e5, 1e7], 5.0, 'BASELINE configs[2]: 2-way 1e5 x 1e7, 5 arcsec'),
+	('c4s', [1e5, 1e6, 1e6], 10.0, 'BASELINE configs[3]: 3-way 1e5 x 1e6 x 1e6, 10 arcsec'),
+	('c5', [5e5, 1e8], 5.0, 'BASELINE configs[4]: 2-way 5e5 x 1e8, 5 arcsec')]
+
+
+def single_gpu_jobs(args, device, names, budget_s=240.0):
+	"""The fixed-size jobs BASELINE names, each as ONE job on ONE GPU (this process's): the N = 1 point of their strong-scaling
+	curves, measured in the same launch and on the same hardware as the N > 1 points of `extra_configs`, so that
+	value(N) / value(1) needs no second run.  Same generators, same seeds' family, same step definition (one pass of the whole
+	path over the resident catalogues).  NWAY_BENCH_EXTRA_SCALE scales the sizes (tests)."""
+	import torch
+	import nway_amd
+	from nway_amd import _hip
+	scale = float(os.environ.get('NWAY_BENCH_EXTRA_SCALE', '1'))
+	out = {}
+	t_start = time.perf_counter()
+	steps, warm = min(args.steps, 20), min(max(args.warmup, 2), 5)
+	for name, sizes, radius, what in FIXED_JOBS:
+		if name not in names:
+			continue
+		if time.perf_counter() - t_start > budget_s:
+			out[name] = dict(skipped='time budget of the single-GPU references (%g s) spent' % budget_s)
+			continue
+		sizes = [max(int(n * scale), 8) for n in sizes]
+		rec = dict(job=what, sizes=sizes, radius_arcsec=radius, n_gpus=1)
+		plan = None
+		try:
+			tabs = list(make_workload(sizes[0], sizes[1], args.seed + 77)) if len(sizes) == 2 else make_workload3(sizes[0], sizes[1], sizes[2], args.seed + 77)
+			k = len(tabs)
+			err = radius / 60. / 60
+			scheme = nway_amd.choose_scheme([(t['ra'], t['dec']) for t in tabs], err)
+			dens, dens_plus = nway_amd._compute_source_densities(tabs, nway_amd.NullOutputLogger())
+			comp = nway_amd._completeness_vector(args.completeness, k)
+			params = _hip.make_params(k, scheme, radius, err, dens, dens_plus, nway_amd._prior_table(dens, dens_plus, comp))
+			cats = [_hip.DeviceCatalogue(t['ra'], t['dec'], np.asarray(t['error'], dtype=float), device) for t in tabs]
+			cap_pairs, cap_rows = nway_amd._estimate_capacities([c.n for c in cats], [SKY_AREA] * k, radius, scheme, True)
+			plan, st = _hip.run_plan([c.n for c in cats], params, cats, cap_pairs, cap_rows, device, lean=True)
+			for _ in range(warm):
+				plan.enqueue(cats)
+			torch.cuda.synchronize(device)
+			t0 = time.perf_counter()
+			for _ in range(steps):
+				plan.enqueue(cats)
+			torch.cuda.synchronize(device)
+			ms = (time.perf_counter() - t0) * 1e3 / steps
+			st = plan.read_status()
+			rows = int(st[_hip.ST_ROWS])
+			jb = job_bytes(sizes, [True] + [False] * (k - 1), rows)
+			rec.update(ms_per_step=ms, steps=steps, rows=rows, value=rows / (ms * 1e-3), flags=int(st[_hip.ST_FLAGS]), job_bytes=jb,
+				pass_frac=jb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, path=plan.description)
+		except Exception as e:
+			rec['error'] = '%s: %s' % (type(e).__name__, e)
+		finally:
+			if plan is not None:
+				plan.close()
+			cats = tabs = None
+			torch.cuda.empty_cache()
+		out[name] = rec
+	return out
+
+
+def fixed_size_summary(extras, n1, world):
+	"""per job BASELINE names: its best N-GPU record of `extra_configs`, the one-GPU run of the same job from the same launch,
+	and their ratio -- the job's strong-scaling speed-up at this N"""
+	out = {}
+	for name, _, _, what in FIXED_JOBS:
+		recs = [r for r in (extras or []) if r.get('job', '').split('_')[0] == name and 'value' in r and not r.get('flags')]
+		best = max(recs, key=lambda r: r['value']) if recs else None
+		one = (n1 or {}).get(name)
+		entry = dict(job=what)
+		if one is not None:
+			entry['one_gpu'] = dict((key, one.get(key)) for key in ('ms_per_step', 'value', 'rows', 'pass_frac', 'error', 'skipped') if key in one)
+		if best is not None:
+			entry['n_gpus'] = world
+			entry['best'] = dict(mode=best['mode'], exchanges=best['exchanges'], ms_per_step=best['ms_per_step'], value=best['value'], rows=best['rows'],
+				pass_frac=best['pass_frac'], ranks_seen=best['ranks_seen'])
+			if one is not None and one.get('value'):
+				entry['speedup_vs_one_gpu'] = best['value'] / one['value']  # (rows per second of the same-sized job; the shards are seeded per rank, so the row counts agree to a fraction of a per cent, not exactly)
+		out[name] = entry
+	return out
+
+
 def main():
 	ap = argparse.ArgumentParser()
 	ap.add_argument('--gpus', type=int, default=1)
@@ -454,6 +536,9 @@ def main():
 		help='who carries the exchanges of the multi-GPU modes: torch.distributed (default) or the library\'s own RCCL calls behind the C ABI (nwayhip_comm_*)')
 	ap.add_argument('--extras', type=int, default=int(os.environ.get('NWAY_BENCH_EXTRAS', '1')),
 		help='N > 1: also measure, in the same launch, the fixed-size jobs BASELINE names for several GPUs (extra_configs: C3-S as one job, configs[3], configs[4]; both sharding modes, both carriers of the exchanges); 0 = skip')
+	ap.add_argument('--fixed-jobs', type=int, default=int(os.environ.get('NWAY_BENCH_FIXED_JOBS', '1')),
+		help='also measure, as ONE job on ONE GPU, the fixed-size jobs BASELINE names (configs[3], configs[4]; with N > 1 also configs[2]): '
+		'the N = 1 point of their strong-scaling curves, in this launch (rank 0, the other ranks wait); 0 = skip')
 	ap.add_argument('--live-traffic', type=int, default=int(os.environ.get('NWAY_BENCH_LIVE_TRAFFIC', '1')),
 		help='N = 1: measure roofline.traffic in this run (two short child runs under rocprofv3 --pmc, ~30 s); 0: the recorded profiles/sweep_traffic.json')
 	ap.add_argument('--streams', type=int, default=int(os.environ.get('NWAY_BENCH_STREAMS', '1')),
@@ -754,6 +839,11 @@ def main():
 			assert out['check']['ok'], 'the timed table differs from the CPU table: %r' % (out['check'],)
 		else:
 			out['cpu_baseline'] = None
+	ranks_seen = 1
+	if world > 1 or force_dist:
+		seen = torch.ones(1, dtype=torch.int64, device=device)
+		dist.all_reduce(seen)
+		ranks_seen = int(seen.item())
 	extras = None
 	if (world > 1 or force_dist) and args.extras:
 		# (every rank takes part; the headline's engine has been measured and is released first)
@@ -765,9 +855,33 @@ def main():
 			plans = []
 			torch.cuda.empty_cache()
 		extras = extra_configs(args, world, rank, device, dist, backend)
+	n1 = None
+	multi = world > 1 or force_dist
+	if args.fixed_jobs and ((multi and args.extras) or (not multi and args.cpu_sample != 0)):
+		# (with N > 1 they belong to the extra_configs block; a profiling / A-B invocation -- --cpu-sample 0 on one GPU -- measures the headline only)
+		if engine is not None and getattr(engine, 'plan', None) is not None:
+			engine.plan.close()
+		engine = None
+		if world == 1 and not force_dist:
+			for pl in plans:
+				pl.close()
+			plans, plan = [], None
+			cats = sec_copies = None
+		torch.cuda.empty_cache()
+		if rank == 0:
+			n1 = single_gpu_jobs(args, device, ['c4s', 'c5'] + (['c3s'] if (world > 1 or force_dist) else []))
+		if world > 1 or force_dist:
+			dist.barrier()  # (the other ranks wait here while rank 0 measures the one-GPU references)
 	if rank == 0:
+		out['ranks_seen'] = ranks_seen
 		if extras is not None:
 			out['extra_configs'] = extras
+		if n1 is not None or extras is not None:
+			out['fixed_size_jobs'] = fixed_size_summary(extras, n1, world)
+			out['fixed_size_jobs_note'] = ('the jobs BASELINE names, fixed in size: `best` = the fastest of this launch\'s extra_configs records of the job over '
+				'%d GPU(s), `one_gpu` = the same job as one job on one GPU measured in this launch, `speedup_vs_one_gpu` their ratio (strong scaling); '
+				'the headline `value` above is %s' % (world, 'the weak-scaling run the bench contract asks for (per-GPU work fixed), N x by construction'
+				if (world > 1 and not strong) else 'the one-GPU run of configs[2]'))
 		print(json.dumps(out))
 	if world > 1 or force_dist:
 		dist.destroy_process_group()

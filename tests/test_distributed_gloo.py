@@ -1,4 +1,4 @@
-"""world_size-2 tests of the sharding logic with the gloo backend on CPU.
+"""world_size 2, 3 and 8 tests of the sharding logic with the gloo backend on CPU.
 
 The HIP kernels cannot run here, so the per-rank compute is the CPU oracle (test
 infrastructure, plugged into the engines' hooks by the subclasses of tests/cpu_engines.py --
@@ -68,7 +68,7 @@ def worker(rank, world, port, outfile):
 		dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('world', [2, 3])
+@pytest.mark.parametrize('world', [2, 3, 8])
 def test_sharded_equals_unsharded(tmp_path, world):
 	import nway_oracle as orc
 	outfile = str(tmp_path / 'gathered.npz')
@@ -99,9 +99,12 @@ def split_worker(rank, world, port, outfile, k):
 	try:
 		from nway_amd import distributed
 		A, B, C = make_catalogues()
-		pb = [0, 150, len(A['ra'])]       # uneven shards of the primaries
-		bb = [0, 3500, len(B['ra'])]      # and of the secondary streams
-		cb = [0, 1200, len(C['ra'])]
+		if world == 2:
+			pb = [0, 150, len(A['ra'])]       # uneven shards of the primaries
+			bb = [0, 3500, len(B['ra'])]      # and of the secondary streams
+			cb = [0, 1200, len(C['ra'])]
+		else:
+			pb, bb, cb = [list(distributed.shard_bounds(len(t['ra']), world)) for t in (A, B, C)]
 		def rows(t, lo, hi):
 			return dict(t, ra=t['ra'][lo:hi], dec=t['dec'][lo:hi], error=t['error'][lo:hi])
 		secs = [rows(B, bb[rank], bb[rank + 1]), rows(C, cb[rank], cb[rank + 1])][:k - 1]
@@ -118,14 +121,14 @@ def split_worker(rank, world, port, outfile, k):
 		dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('k', [2, 3])
-def test_secondary_split_equals_unsharded(tmp_path, k):
+@pytest.mark.parametrize('world,k', [(2, 2), (2, 3), (8, 3)])
+def test_secondary_split_equals_unsharded(tmp_path, world, k):
 	"""every rank sweeps only its slice of the secondaries against ALL primaries; the candidates are
 	routed to the owners of the primaries (all-to-all-v with global indices, uneven slices); the
 	rank-order concatenation of the owners' tables is the unsharded table"""
 	import nway_oracle as orc
 	outfile = str(tmp_path / 'split.npz')
-	mp.spawn(split_worker, args=(2, free_port(), outfile, k), nprocs=2, join=True)
+	mp.spawn(split_worker, args=(world, free_port(), outfile, k), nprocs=world, join=True)
 	got = np.load(outfile)
 	A, B, C = make_catalogues()
 	want = orc.nway_match([A, B, C][:k], 20., 0.85)
@@ -165,7 +168,7 @@ def zone_worker(rank, world, port, outfile, k):
 		# every primary of the job has exactly one owner; the zones' secondaries overlap in the seams only
 		own = torch.tensor([len(zm.zone_primary['ra']), len(zm.zone_secondaries[0]['ra'])], dtype=torch.int64)
 		dist.all_reduce(own)
-		assert int(own[0]) == len(A['ra']) and len(B['ra']) <= int(own[1]) <= 1.2 * len(B['ra'])
+		assert int(own[0]) == len(A['ra']) and len(B['ra']) <= int(own[1]) <= (1.2 if world <= 3 else 1.6) * len(B['ra'])  # (seven seams of +-20 arcsec in a 0.4 degree patch)
 		assert (np.diff(zm.primary_gidx) > 0).all() and (np.diff(zm.sec_gidx[0]) > 0).all()  # (ascending global indices: the rows' order)
 		zm.step()
 		total = zm.total_rows()
@@ -176,7 +179,7 @@ def zone_worker(rank, world, port, outfile, k):
 		dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('world,k', [(2, 2), (2, 3), (3, 3)])
+@pytest.mark.parametrize('world,k', [(2, 2), (2, 3), (3, 3), (8, 3)])
 def test_zone_sharded_equals_unsharded(tmp_path, world, k):
 	"""primaries AND secondaries redistributed by declination zones (edges from the summed histogram of the largest secondary
 	catalogue; the secondaries inside the seams go to both neighbours); the ranks' tables, concatenated and sorted by primary,

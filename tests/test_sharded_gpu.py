@@ -340,3 +340,33 @@ def test_bench_extra_configs_one_rank_both_carriers():
 	assert res.returncode == 0, res.stderr[-3000:]
 	out = json.loads([l for l in res.stdout.splitlines() if l.startswith('{')][-1])
 	check_extra_configs(out, 1, ['torch.distributed', 'nwayhip_comm_*'], 0.02)
+
+
+def test_bench_eight_gloo_ranks_share_the_gpu(tmp_path):
+	"""bench.py as the driver will launch it on an 8-GPU node -- torch.distributed.run, eight ranks -- here with the eight ranks on
+	the ONE GPU over gloo and sizes scaled down: the weak headline, ranks_seen, one job per sharding mode in extra_configs, and the
+	fixed-size summary with the one-GPU references rank 0 measures in the same launch"""
+	env = dict(os.environ, NWAY_BENCH_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0', NWAY_BENCH_EXTRA_SCALE='0.02',
+		NWAY_BENCH_EXTRA_ONLY='c5_zones,c4s_rows,c3s_split')
+	cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '8', '--master-addr', '127.0.0.1',
+		'--master-port', str(free_port()), os.path.join(ROOT, 'bench.py'), '--gpus', '8', '--steps', '4', '--warmup', '2', '--prewarm', '3',
+		'--n-primary', '5000', '--n-secondary', '800000']
+	res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, timeout=1200, env=env, cwd=ROOT)
+	assert res.returncode == 0, res.stderr[-3000:]
+	line = [l for l in res.stdout.splitlines() if l.startswith('{')][-1]
+	out = json.loads(line)
+	assert out['n_gpus'] == 8 and out['ranks_seen'] == 8 and out['scaling'] == 'weak'
+	assert 8 * 5000 * 1.7 < out['config']['rows_per_step'] < 8 * 5000 * 1.9
+	recs = out['extra_configs']
+	assert sorted(r['job'] for r in recs) == ['c3s_split', 'c4s_rows', 'c5_zones']
+	for r in recs:
+		assert 'error' not in r and r['ranks_seen'] == 8 and r['n_gpus'] == 8 and r['flags'] == 0 and r['value'] > 0, r
+	fixed = out['fixed_size_jobs']
+	for name in ('c3s', 'c4s', 'c5'):
+		f = fixed[name]
+		assert f['n_gpus'] == 8 and f['best']['ranks_seen'] == 8 and f['one_gpu']['value'] > 0 and f['speedup_vs_one_gpu'] > 0, f
+		assert abs(f['best']['rows'] - f['one_gpu']['rows']) < 0.05 * f['one_gpu']['rows'], f
+	keep = os.path.join(ROOT, 'gpurun_out')
+	if os.path.isdir(keep):
+		with open(os.path.join(keep, 'bench_x8_gloo.json'), 'w') as f:
+			f.write(line + '\n')
