@@ -109,7 +109,148 @@ def shard_bounds(n, world):
 	return numpy.concatenate([[0], numpy.cumsum(sizes)]).astype(numpy.int64)
 
 
-class ShardedMatch(object):
+
+class MagnitudePriors(object):
+	"""Magnitude (or other property) priors on a SHARDED match (nwaylib/__init__.py:304-396, ``_apply_magnitude_biasing`` and the
+	final probabilities :399-461) -- a mix-in of ``ShardedMatch`` and ``ZoneShardedMatch``.
+
+	What the reference computes on the one table splits into a GLOBAL part -- which sources of a catalogue are secure counterparts
+	and which are field sources decides the two histograms of a column (:324-375) -- and a per-row part (the bias of a row and the
+	statistics of its primary's group, :383-394, :399-461).  The global part needs, of every rank's rows that HAVE a counterpart in
+	the column's catalogue, four small things: the counterpart's index, whether the row is secure / plausible, its weight.  They are
+	gathered (``all_gather_object``; the table itself stays where it is), put into the order of the global table (stable by primary:
+	the reference looks a secure source's weight up at the position of its first secure row, :337 -- the order matters), and every
+	rank then evaluates the SAME selection and histograms with ``magpriors.secure_and_field_sources`` (the code ``nway_match`` itself
+	runs on one GPU).  The per-row part runs on the rank's own rows: ``nwayhip_bias_lookup`` and ``nwayhip_group_stats`` on the device.
+
+	Hooks (the CPU tests fill them with numpy): ``_bias_lookup``, ``_final_probabilities``."""
+
+	def _allgather_column(self, values):
+		"""a column given as this rank's shard / slice (contiguous global rows, rank order) -> the whole column on every rank"""
+		import torch
+		col, _ = allgatherv(torch.as_tensor(numpy.asarray(values, dtype=float)).to(self._exchange_device()), self.group, None)
+		return col.cpu().numpy()
+
+	def _bias_lookup(self, idx, mag_all, func, total):
+		"""log10(func(mag_all[idx])) added to ``total`` in place (undefined -> 0); returns the bias column 10^weight (device kernel)"""
+		from nway_amd import _hip
+		lib = _hip.load()
+		t = _hip.torch()
+		n = len(idx)
+		if n == 0:
+			return numpy.zeros(0)
+		d_idx = _hip.to_device(numpy.asarray(idx, dtype=numpy.int32), self.device)
+		d_mag = _hip.to_device(numpy.where(numpy.isfinite(mag_all), mag_all, numpy.nan), self.device)
+		d_edges = _hip.to_device(func.edges, self.device)
+		d_ratio = _hip.to_device(func.values, self.device)
+		d_total = _hip.to_device(total, self.device)
+		d_bias = t.empty(n, dtype=t.float64, device=self.device)
+		_hip.check(lib.nwayhip_bias_lookup(n, _hip.ptr(d_idx), _hip.ptr(d_mag), len(func.edges), _hip.ptr(d_edges), _hip.ptr(d_ratio),
+			_hip.ptr(d_total), _hip.ptr(d_bias), _hip.current_stream_ptr(self.device)))
+		total[:] = _hip.to_host(d_total)
+		return _hip.to_host(d_bias)
+
+	def _final_probabilities(self, primary_index, ncat, total, prior, ratio):
+		"""p_single, p_any, p_i, match_flag of this rank's rows from the biased totals (device kernel); rows of a primary are contiguous"""
+		from nway_amd import _hip
+		lib = _hip.load()
+		t = _hip.torch()
+		n = len(total)
+		if n == 0:
+			z = numpy.zeros(0)
+			return z, z, z, numpy.zeros(0, dtype=numpy.int64)
+		starts = numpy.flatnonzero(numpy.r_[True, primary_index[1:] != primary_index[:-1]])
+		group_start = numpy.r_[starts, n].astype(numpy.int64)
+		d_gs = _hip.to_device(group_start, self.device)
+		d_total = _hip.to_device(total, self.device)
+		d_prior = _hip.to_device(prior, self.device)
+		out = [t.empty(n, dtype=t.float64, device=self.device) for _ in range(3)]
+		flag = t.empty(n, dtype=t.int8, device=self.device)
+		_hip.check(lib.nwayhip_group_stats(n, len(starts), _hip.ptr(d_gs), _hip.ptr(d_total), _hip.ptr(d_prior), float(ratio), _hip.ptr(out[0]),
+			_hip.ptr(out[1]), _hip.ptr(out[2]), _hip.ptr(flag), _hip.current_stream_ptr(self.device)))
+		return _hip.to_host(out[0]), _hip.to_host(out[1]), _hip.to_host(out[2]), _hip.to_host(flag).astype(numpy.int64)
+
+	def magnitude_priors(self, mags, mag_include_radius=None, mag_exclude_radius=None, magauto_post_single_minvalue=0.9,
+			store_mag_hists=False, logger=None):
+		"""COLLECTIVE (every rank calls it, after ``step()``).  mags: per catalogue, primary first, a list of
+		``(magname, values, maghist)`` -- ``values`` = the column for THIS RANK's shard / slice of the catalogue (as its ra / dec were
+		given), ``maghist`` = None (learn the histogram from the match, "auto") or ``(bins_lo, bins_hi, hist_sel, hist_all)``.
+		Returns this rank's block of the table with the ``bias_*`` columns and p_single / match_flag / prob_has_match /
+		prob_this_match recomputed from the biased totals -- row for row what ``nway_amd.nway_match`` returns on one GPU."""
+		import nway_amd
+		from nway_amd import magnitudeweights, magpriors
+		logger = logger or nway_amd.NullOutputLogger()
+		if mag_exclude_radius is None:
+			mag_exclude_radius = mag_include_radius
+		t = self.local_table()
+		names = [self.primary['name']] + [s['name'] for s in self.secondary_slices]
+		k = len(names)
+		prim = numpy.asarray(t[names[0]], dtype=numpy.int64)
+		n = len(prim)
+		total = numpy.array(t['dist_bayesfactor'], dtype=float) if n else numpy.zeros(0)
+		dist = _dist()
+		for c, columns in enumerate(mags):
+			for magname, values, maghist in columns:
+				col = '%s_%s' % (names[c], magname)
+				mag = '%s:%s' % (names[c], magname)
+				mag_all = self._allgather_column(values) if self.world > 1 else numpy.array(values, dtype=float)
+				mag_all[mag_all == -99] = numpy.nan
+				idx = numpy.asarray(t[names[c]], dtype=numpy.int64)
+				if maghist is None:
+					if mag_include_radius is not None:
+						sep_max = numpy.asarray(t['Separation_max'])
+						secure, plausible, weights = sep_max < mag_include_radius, sep_max < mag_exclude_radius, numpy.ones(n)
+					else:
+						post = numpy.asarray(t['dist_post'])
+						secure, plausible, weights = post > magauto_post_single_minvalue, post > 0.01, post
+					present = idx != -1
+					mine = (prim[present], idx[present], numpy.asarray(secure)[present], numpy.asarray(plausible)[present], numpy.asarray(weights, dtype=float)[present])
+					if self.world > 1:
+						parts = [None] * self.world
+						dist.all_gather_object(parts, mine, group=self.group)
+					else:
+						parts = [mine]
+					g = [numpy.concatenate([numpy.asarray(part[i]) for part in parts]) for i in range(5)]
+					order = numpy.argsort(g[0], kind='stable')  # the global table's order: by primary, a primary's rows as its rank has them
+					target, target_weights, field, n_plausible = magpriors.secure_and_field_sources(g[1][order], mag_all, g[2][order].astype(bool),
+						g[3][order].astype(bool), g[4][order], 'api', mag)
+					logger.log('magnitude histogram of column "%s": %d secure matches, %d insecure matches and %d secure non-matches of %d total entries (%d valid)'
+						% (col, len(target), n_plausible, field.sum(), len(mag_all), numpy.isfinite(mag_all).sum()))
+					bins, hist_sel, hist_all = magnitudeweights.adaptive_histograms(mag_all[field], target, weights=target_weights)
+					if store_mag_hists and self.rank == 0:
+						magpriors.write_histogram(mag.replace(':', '_') + '_fit.txt', bins, hist_sel, hist_all)
+					if len(target) < 100:
+						raise nway_amd.UndersampledException('ERROR: too few secure matches (%d) to make a good histogram. If you are sure you want to use this poorly sampled histogram, replace "auto" with the filename. You can also decrease the mag-auto-minprob parameter.' % len(target))
+				else:
+					bins_lo, bins_hi, hist_sel, hist_all = maghist
+					bins = numpy.array(list(bins_lo) + [bins_hi[-1]])
+				func = magnitudeweights.fitfunc_histogram(bins, hist_sel, hist_all)
+				t['bias_%s' % col] = self._bias_lookup(idx, mag_all, func, total)
+		# the prior of a row follows from which catalogues it has (__init__.py:254), with the densities of the WHOLE catalogues
+		comp = nway_amd._completeness_vector(self.prior_completeness, k)
+		table = nway_amd._prior_table(numpy.asarray(self.dens), numpy.asarray(self.dens_plus), comp)
+		pattern = numpy.zeros(n, dtype=numpy.int64)
+		for c in range(1, k):
+			pattern |= (numpy.asarray(t[names[c]]) >= 0).astype(numpy.int64) << (c - 1)
+		prior = table[pattern]
+		p_single, p_any, p_i, flag = self._final_probabilities(prim, numpy.asarray(t['ncat']), total, prior, self.prob_ratio_secondary)
+		t['p_single'], t['prob_has_match'], t['prob_this_match'], t['match_flag'] = p_single, p_any, p_i, flag
+		return t
+
+	def gather_magnitude_table(self, local, dst=0):
+		"""the global table of ``magnitude_priors`` on rank ``dst`` (sorted by primary), None elsewhere"""
+		if self.world == 1:
+			return local
+		gathered = [None] * self.world if self.rank == dst else None
+		_dist().gather_object(local, gathered, dst=dst, group=self.group)
+		if self.rank != dst:
+			return None
+		out = dict((key, numpy.concatenate([numpy.asarray(g[key]) for g in gathered])) for key in gathered[0] if not key.startswith('_'))
+		order = numpy.argsort(out[self.primary['name']], kind='stable')
+		return dict((key, v[order]) for key, v in out.items())
+
+
+class ShardedMatch(MagnitudePriors):
 	"""Primary rows sharded over the ranks, secondary catalogues replicated by all-gatherv.
 
 	primary: this rank's shard of the primary catalogue (dict: name, ra, dec, error, area)
@@ -179,6 +320,10 @@ class ShardedMatch(object):
 		self.primary_offset = int(sum(self.primary_sizes[:self.rank]))
 		self._sync()
 		self.setup_seconds = time.perf_counter() - t0
+		import nway_amd
+		self.dens, self.dens_plus = nway_amd._densities_from_sizes([self.primary['name']] + [f['name'] for f in self.full_secondaries],
+			[int(sum(self.primary_sizes))] + [int(f['ra'].shape[0]) for f in self.full_secondaries],
+			[self.primary['area']] + [f['area'] for f in self.full_secondaries], nway_amd.NullOutputLogger())
 		self._build_plan()
 
 	def _tables(self):
@@ -653,7 +798,7 @@ def exchange_rows(rows, send_counts, group=None):
 	return out.to(dev) if on_host else out
 
 
-class ZoneShardedMatch(object):
+class ZoneShardedMatch(MagnitudePriors):
 	"""ONE job over several GPUs with BOTH sides sharded by declination zones (what BASELINE configs[4] calls pre-bucketing,
 	done across the GPUs): rank z owns the primaries whose declination lies in zone z and holds the secondaries within the
 	match radius of that zone -- a great-circle separation is at least the difference of the declinations, so every

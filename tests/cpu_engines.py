@@ -17,7 +17,28 @@ sys.path.insert(0, os.path.join(ROOT, 'oracle'))
 from nway_amd import distributed  # noqa: E402
 
 
-class OracleShardedMatch(distributed.ShardedMatch):
+class NumpyMagnitudeHooks(object):
+	"""the two per-row hooks of distributed.MagnitudePriors in numpy (the HIP engines run nwayhip_bias_lookup / nwayhip_group_stats)"""
+
+	def _bias_lookup(self, idx, mag_all, func, total):
+		idx = np.asarray(idx, dtype=np.int64)
+		m = np.where(idx >= 0, mag_all[np.maximum(idx, 0)] if len(mag_all) else np.nan, np.nan)
+		with np.errstate(divide='ignore'):
+			w = np.log10(func(m))
+		w[np.isnan(w)] = 0
+		total += w
+		return 10**w
+
+	def _final_probabilities(self, primary_index, ncat, total, prior, ratio):
+		import nway_oracle as orc
+		if len(total) == 0:
+			return np.zeros(0), np.zeros(0), np.zeros(0), np.zeros(0, dtype=np.int64)
+		p_single = orc.posterior(prior, total)
+		p_any, p_i, flag = orc.group_statistics(np.asarray(primary_index), orc.unnormalised_log_posterior(prior, total, np.asarray(ncat)), ratio)
+		return p_single, p_any, p_i, flag
+
+
+class OracleShardedMatch(NumpyMagnitudeHooks, distributed.ShardedMatch):
 	"""primary rows sharded, secondaries all-gathered; the per-rank match is the numpy oracle"""
 
 	def _exchange_device(self):
@@ -128,7 +149,7 @@ class OracleSecondarySplitMatch(distributed.SecondarySplitMatch):
 		return dict(self.table)
 
 
-class OracleZoneShardedMatch(distributed.ZoneShardedMatch):
+class OracleZoneShardedMatch(NumpyMagnitudeHooks, distributed.ZoneShardedMatch):
 	"""both sides sharded by declination zones (one all-to-all-v of rows at set-up, through gloo); the match of a zone is the
 	numpy oracle with the densities and the cell scheme of the whole catalogues"""
 

@@ -259,3 +259,64 @@ def test_zone_sharded_edge_cases(tmp_path, case):
 		if key.startswith('_'):
 			continue
 		np.testing.assert_array_equal(got[key], want[key], err_msg=key)
+
+
+# ---- magnitude priors on a sharded match (distributed.MagnitudePriors): selection gathered, histograms on every rank, rows local ----
+
+def mag_worker(rank, world, port, outfile, mode, which):
+	os.environ['MASTER_ADDR'] = '127.0.0.1'
+	os.environ['MASTER_PORT'] = str(port)
+	dist.init_process_group('gloo', rank=rank, world_size=world)
+	try:
+		from nway_amd import distributed
+		from cpu_engines import OracleShardedMatch, OracleZoneShardedMatch
+		from goldenutil import mag3_tables, magmix_tables
+		tabs = mag3_tables() if which == 'mag3' else magmix_tables()
+		radius, comp, kw = (20., 0.9, {}) if which == 'mag3' else (12., np.array([1.0, 0.8, 0.7]), dict(mag_include_radius=1.5, mag_exclude_radius=6.0))
+		bounds = [distributed.shard_bounds(len(t['ra']), world) for t in tabs]
+		if world == 2:
+			bounds[0] = [0, len(tabs[0]['ra']) // 3, len(tabs[0]['ra'])]  # (uneven shards)
+		def rows(t, b):
+			return dict(t, ra=t['ra'][b[rank]:b[rank + 1]], dec=t['dec'][b[rank]:b[rank + 1]], error=t['error'][b[rank]:b[rank + 1]], mags=[], magnames=[], maghists=[])
+		cls = OracleShardedMatch if mode == 'rows' else OracleZoneShardedMatch
+		eng = cls(rows(tabs[0], bounds[0]), [rows(t, b) for t, b in zip(tabs[1:], bounds[1:])], radius, comp, device=torch.device('cpu'))
+		eng.step()
+		mags = [[(n, np.array(v[b[rank]:b[rank + 1]]), h) for n, v, h in zip(t['magnames'], t['mags'], t['maghists'])] for t, b in zip(tabs, bounds)]
+		local = eng.magnitude_priors(mags, **kw)
+		table = eng.gather_magnitude_table(local, dst=0)
+		if rank == 0:
+			np.savez(outfile, **table)
+	finally:
+		dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('mode,world', [('rows', 2), ('zones', 3)])
+def test_sharded_magnitude_priors_three_way_golden(tmp_path, mode, world):
+	"""the shape of BASELINE configs[1] -- XMM x OPT x IRAC, three magnitude columns over two catalogues, histograms learned from the
+	posterior-selected matches -- over several ranks (primary rows sharded / declination zones): the gathered table equals the
+	REFERENCE's table of the one-process run (tests/golden/mag3.npz)"""
+	from goldenutil import golden, assert_table_matches, assert_checksums_match
+	outfile = str(tmp_path / 'mag.npz')
+	mp.spawn(mag_worker, args=(world, free_port(), outfile, mode, 'mag3'), nprocs=world, join=True)
+	t = dict(np.load(outfile))
+	g = golden('mag3')
+	names = ['XMM', 'OPT', 'IRAC']
+	assert_checksums_match(t, g, 'm3_', names)
+	rows = g['m3_sub_rows']
+	assert_table_matches(t, g, 'm3_sub_', names, rows=rows, rtol=1e-9, atol=1e-13)
+	for b in ('bias_OPT_R', 'bias_OPT_I', 'bias_IRAC_CH1'):
+		np.testing.assert_allclose(np.asarray(t[b])[rows], g['m3_sub_' + b], rtol=1e-9, err_msg=b)
+		np.testing.assert_allclose(np.sum(t[b]), g['m3_sum_' + b][0], rtol=1e-9, err_msg=b)
+
+
+def test_sharded_magnitude_priors_on_every_catalogue_golden(tmp_path):
+	"""magnitude columns on the PRIMARY (supplied histogram) and on both secondaries (learned by radius, exclusion radius apart),
+	primary rows sharded over two ranks: the reference's table (tests/golden/magmix.npz)"""
+	from goldenutil import golden, assert_table_matches
+	outfile = str(tmp_path / 'magmix.npz')
+	mp.spawn(mag_worker, args=(2, free_port(), outfile, 'rows', 'magmix'), nprocs=2, join=True)
+	t = dict(np.load(outfile))
+	g = golden('magmix')
+	assert_table_matches(t, g, 'rad_', ['P', 'A', 'B'], rtol=1e-9, atol=1e-13)
+	for b in ('bias_P_F', 'bias_A_M', 'bias_B_M'):
+		np.testing.assert_allclose(t[b], g['rad_' + b], rtol=1e-9, err_msg=b)
