@@ -139,7 +139,7 @@ class MagnitudePriors(object):
 		n = len(idx)
 		if n == 0:
 			return numpy.zeros(0)
-		d_idx = _hip.to_device(numpy.asarray(idx, dtype=numpy.int32), self.device)
+		d_idx = _hip.to_device(numpy.asarray(idx, dtype=numpy.int32), self.device, dtype=t.int32)
 		d_mag = _hip.to_device(numpy.where(numpy.isfinite(mag_all), mag_all, numpy.nan), self.device)
 		d_edges = _hip.to_device(func.edges, self.device)
 		d_ratio = _hip.to_device(func.values, self.device)
@@ -161,7 +161,7 @@ class MagnitudePriors(object):
 			return z, z, z, numpy.zeros(0, dtype=numpy.int64)
 		starts = numpy.flatnonzero(numpy.r_[True, primary_index[1:] != primary_index[:-1]])
 		group_start = numpy.r_[starts, n].astype(numpy.int64)
-		d_gs = _hip.to_device(group_start, self.device)
+		d_gs = _hip.to_device(group_start, self.device, dtype=t.int64)
 		d_total = _hip.to_device(total, self.device)
 		d_prior = _hip.to_device(prior, self.device)
 		out = [t.empty(n, dtype=t.float64, device=self.device) for _ in range(3)]
