@@ -120,9 +120,11 @@ def cpu_baseline(primary, secondary, radius, completeness, numpy_sample):
 	for name, threads in (('all_cores', 0), ('one_core', 1)):
 		if threads == 0 and cores == 1:
 			continue
-		t0 = time.perf_counter()
-		table = nway_oracle_c.nway_match([primary, sec], radius, completeness, threads=threads)
-		dt = time.perf_counter() - t0
+		dt = None
+		for rep in range(2 if threads == 0 else 1):  # (all cores: the better of two -- the first call also starts the thread pool)
+			t0 = time.perf_counter()
+			table = nway_oracle_c.nway_match([primary, sec], radius, completeness, threads=threads)
+			dt = min(dt, time.perf_counter() - t0) if dt is not None else time.perf_counter() - t0
 		legs[name] = dict(value=len(table['ncat']) / dt, cores=(cores if threads == 0 else 1), seconds=dt, rows=len(table['ncat']))
 	import nway_oracle
 	m = min(numpy_sample, n)
@@ -134,9 +136,11 @@ def cpu_baseline(primary, secondary, radius, completeness, numpy_sample):
 	best = legs.get('all_cores', legs['one_core'])
 	out = dict(value=best['value'], unit='candidate evaluations/s', cores=best['cores'], kind='port',
 		sample='oracle/nway_oracle.c built with -fopenmp, %d threads (os.sched_getaffinity): the whole workload, %d primaries x %d secondaries, '
-			'%d rows in %.2f s -- NOT a tuned CPU code: the declination sort of the secondaries is per-thread chunk sorts + a pairwise merge tree whose last '
-			'levels run on few threads, the key fill and the final concatenation are serial; the one-core leg beside it is the like-for-like figure' % (
+			'%d rows in %.3f s (the better of two calls) -- a declination-sorted sweep: parallel sample sort of the secondaries (splitters, per-thread bucket '
+			'counts, scatter, independent bucket sorts), then every thread a contiguous range of primaries (binary search + exact test of the band); '
+			'the one-core leg beside it runs the same code on one thread' % (
 			best['cores'], len(primary['ra']), n, best['rows'], best['seconds']),
+		speedup_all_cores_vs_one=(legs['all_cores']['value'] / legs['one_core']['value'] if 'all_cores' in legs else None),
 		one_core=legs['one_core'], numpy_one_thread=legs['numpy_one_thread'],
 		reference_note='the reference itself (pure Python, one thread; it cannot travel to the GPU box) measured in the build container '
 			'on its own fixtures: 8.4e4 rows/s (tests/elltest 2-way, 37 706 rows in 0.45 s), 5.3e4 rows/s (3-way, 450 435 rows in 8.5 s)')
