@@ -135,12 +135,14 @@ def cpu_baseline(primary, secondary, radius, completeness, numpy_sample):
 		sample='all %d primaries x first %d secondaries' % (len(primary['ra']), m))
 	best = legs.get('all_cores', legs['one_core'])
 	out = dict(value=best['value'], unit='candidate evaluations/s', cores=best['cores'], kind='port',
-		sample='oracle/nway_oracle.c built with -fopenmp, %d threads (os.sched_getaffinity): the whole workload, %d primaries x %d secondaries, '
+		sample='oracle/nway_oracle.c built with -fopenmp, %d threads: the whole workload, %d primaries x %d secondaries, '
 			'%d rows in %.3f s (the better of two calls) -- a declination-sorted sweep: parallel sample sort of the secondaries (splitters, per-thread bucket '
 			'counts, scatter, independent bucket sorts), then every thread a contiguous range of primaries (binary search + exact test of the band); '
 			'the one-core leg beside it runs the same code on one thread' % (
 			best['cores'], len(primary['ra']), n, best['rows'], best['seconds']),
 		speedup_all_cores_vs_one=(legs['all_cores']['value'] / legs['one_core']['value'] if 'all_cores' in legs else None),
+		cores_note='cores = what this process can use: %d logical CPUs visible (os.sched_getaffinity), cgroup CPU quota %s' % (
+			nway_oracle_c.visible_cores(), ('%.1f CPUs' % nway_oracle_c.cpu_quota()) if nway_oracle_c.cpu_quota() is not None else 'none'),
 		one_core=legs['one_core'], numpy_one_thread=legs['numpy_one_thread'],
 		reference_note='the reference itself (pure Python, one thread; it cannot travel to the GPU box) measured in the build container '
 			'on its own fixtures: 8.4e4 rows/s (tests/elltest 2-way, 37 706 rows in 0.45 s), 5.3e4 rows/s (3-way, 450 435 rows in 8.5 s)')

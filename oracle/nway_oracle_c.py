@@ -44,12 +44,41 @@ def load(build=True, omp=False):
 	return _libs[omp]
 
 
-def host_cores():
-	"""cores this process may run on"""
+def visible_cores():
+	"""logical CPUs this process may be scheduled on"""
 	try:
 		return len(os.sched_getaffinity(0))
 	except AttributeError:
 		return os.cpu_count() or 1
+
+
+def cpu_quota():
+	"""CPUs' worth of time the container's cgroup grants (cpu.max of cgroup v2, cfs quota of v1), or None without a limit"""
+	try:
+		quota, period = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
+		if quota != 'max':
+			return float(quota) / float(period)
+	except (IOError, OSError, ValueError):
+		pass
+	try:
+		quota = float(open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read())
+		period = float(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+		if quota > 0:
+			return quota / period
+	except (IOError, OSError, ValueError):
+		pass
+	return None
+
+
+def host_cores():
+	"""cores this process can actually USE: the CPUs it may be scheduled on, capped by the cgroup's quota.  (The GPU boxes of this
+	pool show 256 logical CPUs under a quota of 16: 256 threads then share 16 CPUs' worth of time and spend it in each other's
+	barriers -- the all-core leg of round 4 was measured that way.)"""
+	n = visible_cores()
+	q = cpu_quota()
+	if q is not None:
+		n = max(1, min(n, int(q + 0.999)))
+	return n
 
 
 def _copy(ptr, n, dtype):
