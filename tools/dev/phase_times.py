@@ -21,19 +21,26 @@ import bench  # noqa: E402
 import nway_amd  # noqa: E402
 from nway_amd import _hip  # noqa: E402
 
-n0 = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
-n1 = int(sys.argv[2]) if len(sys.argv) > 2 else 10000000
-primary, secondary = bench.make_workload(n0, n1, 1)
-tables = [primary, secondary]
+three = len(sys.argv) > 1 and sys.argv[1] == 'c4s'   # BASELINE configs[3]: 3-way 1e5 x 1e6 x 1e6, 10 arcsec (tail: k_tail3q)
+if three:
+	tables = bench.make_workload3(100000, 1000000, 1000000, 3)
+	radius = 10.
+else:
+	n0 = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
+	n1 = int(sys.argv[2]) if len(sys.argv) > 2 else 10000000
+	primary, secondary = bench.make_workload(n0, n1, 1)
+	tables = [primary, secondary]
+	radius = 5.
+k = len(tables)
 log = nway_amd.NullOutputLogger()
-err = 5. / 3600
+err = radius / 3600
 scheme = nway_amd.choose_scheme([(t['ra'], t['dec']) for t in tables], err)
 dens, dens_plus = nway_amd._compute_source_densities(tables, log)
-comp = nway_amd._completeness_vector(0.9, 2)
-params = _hip.make_params(2, scheme, 5., err, dens, dens_plus, nway_amd._prior_table(dens, dens_plus, comp))
+comp = nway_amd._completeness_vector(0.9, k)
+params = _hip.make_params(k, scheme, radius, err, dens, dens_plus, nway_amd._prior_table(dens, dens_plus, comp))
 cats = [_hip.DeviceCatalogue(t['ra'], t['dec'], np.asarray(t['error'], dtype=float), dev) for t in tables]
 sizes = [c.n for c in cats]
-cap_pairs, cap_rows = nway_amd._estimate_capacities(sizes, [bench.SKY_AREA] * 2, 5., scheme, True)
+cap_pairs, cap_rows = nway_amd._estimate_capacities(sizes, [bench.SKY_AREA] * k, radius, scheme, True)
 plan, st = _hip.run_plan(sizes, params, cats, cap_pairs, cap_rows, dev, lean=True)
 for _ in range(5):
 	plan.enqueue(cats)
@@ -42,6 +49,8 @@ fused = os.environ.get('NWAYHIP_FUSED_FRONT', '0') == '1'  # (front.inc: the reg
 names = {0: ('k_register_x', ['start', None, 'claims + stores landed', 'end']),
 	1: ('k_sweep', ['start', 'bitmap in LDS', 'wave 0 done streaming', 'all waves done', 'probes landed', 'end', 'barrier passed', 'parked tiles tested']),
 	2: ('k_tail2', ['start', 'cnt/slot/sigma landed', 'block scan', 'lookback', 'rows landed', 'group stats landed', 'items set up', 'separations done'])}
+if three:
+	names[2] = ('k_tail3q', ['start', 'exact tests done', 'counts ready (scan word)', 'rows + statistics in registers', 'look-back done', 'rows written'])
 if fused:
 	names[0] = ('registration inside the sweep launch (times since the first SWEEP workgroup started)', [None, 'slice parked (all waves)', 'claims + stores landed', 'announced'])
 acc = {}
@@ -78,6 +87,7 @@ for k, (kname, labels) in names.items():
 		print('%-14s %-26s p10 %6.2f p50 %6.2f p90 %6.2f p99 %6.2f max %6.2f  slowest workgroups %s' % (kname[:14], lab, np.percentile(v, 10), np.percentile(v, 50),
 			np.percentile(v, 90), np.percentile(v, 99), v.max(), list(np.flatnonzero(used)[order[-6:]])))
 first = t[1][t[1][:, 0] > 0][:, 0].min() if fused else t[0][t[0][:, 0] > 0][:, 0].min()
+print('plan: %s' % plan.description)
 print('last run: %s start -> sweep start %.2f us, sweep start -> tail start %.2f us, tail start -> tail end %.2f us' % (
 	'sweep' if fused else 'register', t[1][t[1][:, 0] > 0][:, 0].min() - first, t[2][t[2][:, 0] > 0][:, 0].min() - t[1][t[1][:, 0] > 0][:, 0].min(),
 	t[2][t[2][:, 0] > 0][:, 5].max() - t[2][t[2][:, 0] > 0][:, 0].min()))
