@@ -534,7 +534,7 @@ def main():
 	ap.add_argument('--scaling', choices=['weak', 'strong'], default='weak')
 	ap.add_argument('--sec-buffers', type=int, default=3, help='distinct device copies of the secondary catalogue the steps alternate over')
 	ap.add_argument('--cpu-sample', type=int, default=1000000, help='secondaries in the numpy leg of the CPU baseline (0 = no CPU baseline at all)')
-	ap.add_argument('--event-every', type=int, default=0, help='every n-th sweep launch of the timed region carries a HIP event pair (0 = choose: 2 for --steps <= 24, so that a short run still has >= 10 timed launches; 8 otherwise)')
+	ap.add_argument('--event-every', type=int, default=0, help='every n-th sweep launch of the timed region carries a HIP event pair (0 = choose: 2 for --steps <= 24, 4 below 96, 8 from there: a short run still has >= 10 timed launches)')
 	ap.add_argument('--profile-stages', action='store_true', help='also time every stage (adds event records to the region)')
 	ap.add_argument('--prewarm', type=int, default=200, help='untimed steps before the W warm-up steps: the first ~10 ms after an idle period run at lower clocks (20 steps right after start-up: 82 us each, after 200: 78.5)')
 	ap.add_argument('--two-pipelines', type=int, default=1, help='also time the steps alternating over two (or this many, if > 2) independent pipelines (reported beside, never as, `value`); 0 = skip')
@@ -706,7 +706,7 @@ def main():
 	for _ in range(max(args.prewarm, 0) + args.warmup):
 		step()
 	mask = (1 << _hip.STAGES) - 1 if args.profile_stages else (1 << 1)
-	event_every = args.event_every if args.event_every > 0 else (2 if args.steps <= 24 else 8)
+	event_every = args.event_every if args.event_every > 0 else (2 if args.steps <= 24 else (4 if args.steps < 96 else 8))  # (>= 10 timed sweeps from 20 steps on)
 	for pl in plans:
 		pl.profile(mask, 1 if args.profile_stages else event_every)
 	barrier()
