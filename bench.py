@@ -429,7 +429,9 @@ def extra_configs(args, world, rank, device, dist, backend):
 				rec['error'] = '%s: %s' % (type(e).__name__, e)
 			finally:
 				if engine is not None:
-					if getattr(engine, 'plan', None) is not None:
+					if hasattr(engine, 'close'):
+						engine.close()
+					elif getattr(engine, 'plan', None) is not None:
 						engine.plan.close()
 					if getattr(engine, 'comm', None) is not None:
 						engine.comm.close()
@@ -489,6 +491,30 @@ def single_gpu_jobs(args, device, names, budget_s=240.0):
 			jb = job_bytes(sizes, [True] + [False] * (k - 1), rows)
 			rec.update(ms_per_step=ms, steps=steps, rows=rows, value=rows / (ms * 1e-3), flags=int(st[_hip.ST_FLAGS]), job_bytes=jb,
 				pass_frac=jb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, path=plan.description)
+			if name == 'c5' and os.environ.get('NWAY_BENCH_LOCAL_ZONES', '1') != '0':
+				# the same job with the catalogues bucketed into declination zones at set-up (ZoneShardedMatch on ONE rank, round 5): every
+				# zone's cell table fits the LDS of a sweep workgroup, where the job as one zone needs the large-table sweep
+				plan.close()
+				plan = None
+				cats = None
+				torch.cuda.empty_cache()
+				from nway_amd import distributed
+				eng = distributed.ZoneShardedMatch(tabs[0], tabs[1:], radius, args.completeness, device, zones_per_rank=8, streams=2)
+				try:
+					for _ in range(warm):
+						eng.step()
+					torch.cuda.synchronize(device)
+					t0 = time.perf_counter()
+					for _ in range(steps):
+						eng.step()
+					torch.cuda.synchronize(device)
+					msz = (time.perf_counter() - t0) * 1e3 / steps
+					stz = eng.read_status()
+					rec['zones'] = dict(zones=8, streams=2, ms_per_step=msz, rows=int(stz[_hip.ST_ROWS]), value=int(stz[_hip.ST_ROWS]) / (msz * 1e-3), flags=int(stz[_hip.ST_FLAGS]),
+						pass_frac=jb / (msz * 1e-3) / 1e9 / HBM_PEAK_GBS, setup_s=eng.setup_seconds,
+						note='ZoneShardedMatch(zones_per_rank=8, streams=2) on one rank: the one-time bucketing of the catalogues by zone is set-up, like the exchanges of the multi-GPU modes')
+				finally:
+					eng.close()
 		except Exception as e:
 			rec['error'] = '%s: %s' % (type(e).__name__, e)
 		finally:
@@ -511,12 +537,16 @@ def fixed_size_summary(extras, n1, world):
 		entry = dict(job=what)
 		if one is not None:
 			entry['one_gpu'] = dict((key, one.get(key)) for key in ('ms_per_step', 'value', 'rows', 'pass_frac', 'error', 'skipped') if key in one)
+			if one.get('zones'):
+				entry['one_gpu_zones'] = one['zones']
 		if best is not None:
 			entry['n_gpus'] = world
 			entry['best'] = dict(mode=best['mode'], exchanges=best['exchanges'], ms_per_step=best['ms_per_step'], value=best['value'], rows=best['rows'],
 				pass_frac=best['pass_frac'], ranks_seen=best['ranks_seen'])
 			if one is not None and one.get('value'):
 				entry['speedup_vs_one_gpu'] = best['value'] / one['value']  # (rows per second of the same-sized job; the shards are seeded per rank, so the row counts agree to a fraction of a per cent, not exactly)
+				if one.get('zones') and not one['zones'].get('flags'):
+					entry['speedup_vs_best_one_gpu'] = best['value'] / max(one['value'], one['zones']['value'])  # (against the faster of the two one-GPU runs)
 		out[name] = entry
 	return out
 

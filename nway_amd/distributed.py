@@ -29,6 +29,12 @@ def _dist():
 	return dist
 
 
+def ctypes_stream(stream):
+	"""a torch stream as the ``void*`` the C ABI takes"""
+	import ctypes
+	return ctypes.c_void_p(stream.cuda_stream)
+
+
 def world_info(group=None):
 	dist = _dist()
 	if dist.is_available() and dist.is_initialized():
@@ -825,7 +831,13 @@ class ZoneShardedMatch(MagnitudePriors):
 	ZONE_BINS = 1 << 16
 
 	def __init__(self, primary, secondaries, match_radius, prior_completeness, device, group=None,
-			prob_ratio_secondary=0.5, tuning=None, comm=None):
+			prob_ratio_secondary=0.5, tuning=None, comm=None, zones_per_rank=1, streams=1):
+		"""zones_per_rank: every rank holds this many declination zones and runs them one after the other in a step (round 5).
+		A zone is an ordinary match of its own: several small zones keep the cell table of each within the LDS of a sweep
+		workgroup where the one big zone would need the large-table sweep (5e5 x 1e8 on ONE GPU: 729 us as one zone) -- and with
+		``streams`` > 1 the zones of a step are enqueued round robin on that many HIP streams, so that the latency-bound ends of
+		one zone's pass (registration, routing chain, tail) run beside the stream of another's.  The table does not depend on
+		either number."""
 		if isinstance(secondaries, dict):
 			secondaries = [secondaries]
 		if comm not in (None, 'torch'):
@@ -842,6 +854,8 @@ class ZoneShardedMatch(MagnitudePriors):
 		self.group = group
 		self.tuning = tuning
 		self.rank, self.world = world_info(group)
+		self.zones_per_rank = max(1, int(zones_per_rank))
+		self.nstreams = max(1, int(streams))
 		self.plan = None
 		self.setup_seconds = None
 		self.setup()
@@ -866,7 +880,7 @@ class ZoneShardedMatch(MagnitudePriors):
 		return [int(s.item()) for s in sizes]
 
 	def _zone_edges(self):
-		"""interior edges (world - 1 of them, ascending) of the declination zones: equal shares of the largest secondary catalogue"""
+		"""interior edges (world x zones_per_rank - 1 of them, ascending) of the declination zones: equal shares of the largest secondary catalogue"""
 		import torch
 		dist = _dist()
 		dev = self._exchange_device()
@@ -877,8 +891,9 @@ class ZoneShardedMatch(MagnitudePriors):
 		if self.world > 1:
 			dist.all_reduce(lim, op=dist.ReduceOp.MIN, group=self.group)
 		lo, hi = float(lim[0].item()), -float(lim[1].item())
+		nz = self.world * self.zones_per_rank
 		if not (hi > lo):
-			return numpy.full(self.world - 1, lo if numpy.isfinite(lo) else 0.0)
+			return numpy.full(nz - 1, lo if numpy.isfinite(lo) else 0.0)
 		width = (hi - lo) / self.ZONE_BINS
 		hist = numpy.bincount(numpy.minimum(((dec - lo) / width).astype(numpy.int64), self.ZONE_BINS - 1), minlength=self.ZONE_BINS).astype(numpy.int64)
 		h = torch.as_tensor(hist).to(dev)
@@ -887,8 +902,8 @@ class ZoneShardedMatch(MagnitudePriors):
 		cum = numpy.cumsum(h.cpu().numpy())
 		total = int(cum[-1])
 		edges = []
-		for z in range(1, self.world):
-			b = int(numpy.searchsorted(cum, (total * z) // self.world, side='left'))
+		for z in range(1, nz):
+			b = int(numpy.searchsorted(cum, (total * z) // nz, side='left'))
 			edges.append(lo + (b + 1) * width)
 		return numpy.maximum.accumulate(numpy.asarray(edges, dtype=float))
 
@@ -912,37 +927,55 @@ class ZoneShardedMatch(MagnitudePriors):
 		margin = self.match_radius / 3600. * (1 + 1e-9) + 1e-12
 		self.moved_bytes = 0
 
+		zpr = self.zones_per_rank
+		nz = world * zpr
+
 		def redistribute(table, offset, seams):
-			"""rows of ``table`` -> the ranks of their zones; returns host columns (ra, dec, error or scalar, global index)"""
+			"""rows of ``table`` -> the ranks of their zones; returns per LOCAL zone (host-side bookkeeping aside, the columns stay where
+			they arrived) a table dict and the global indices of its rows"""
 			ra = numpy.asarray(table['ra'], dtype=float)
 			dec = numpy.asarray(table['dec'], dtype=float)
 			scalar_error = numpy.ndim(table['error']) == 0
-			n = len(ra)
 			z_lo = numpy.searchsorted(self.edges, dec - (margin if seams else 0.0), side='right')
 			z_hi = numpy.searchsorted(self.edges, dec + (margin if seams else 0.0), side='right')
 			bad = ~numpy.isfinite(dec)
-			z_lo[bad] = z_hi[bad] = world - 1  # (a source without a declination matches nothing; a primary still has its row)
-			picks, counts = [], []
-			for z in range(world):
+			z_lo[bad] = z_hi[bad] = nz - 1  # (a source without a declination matches nothing; a primary still has its row)
+			picks, counts, zone_of = [], [0] * world, []
+			for z in range(nz):
 				rows = numpy.flatnonzero((z_lo <= z) & (z <= z_hi))
 				picks.append(rows)
-				counts.append(len(rows))
+				zone_of.append(numpy.full(len(rows), float(z)))
+				counts[z // zpr] += len(rows)
 			rows = numpy.concatenate(picks) if picks else numpy.zeros(0, dtype=numpy.int64)
 			cols = [ra[rows], dec[rows]] + ([] if scalar_error else [numpy.asarray(table['error'], dtype=float)[rows]]) + [(rows + offset).astype(float)]
+			if zpr > 1:
+				cols.append(numpy.concatenate(zone_of) if zone_of else numpy.zeros(0))
 			packed = torch.as_tensor(numpy.ascontiguousarray(numpy.stack(cols, axis=1))).to(dev)
 			self.moved_bytes += int(packed.numel()) * 8
 			got = exchange_rows(packed, counts, self.group)
-			# (the columns stay where they arrived -- on the GPU in the product, tensors the plan takes as they are; the global
-			# indices are host-side bookkeeping)
-			out = dict(name=table['name'], ra=got[:, 0].contiguous(), dec=got[:, 1].contiguous(), area=table['area'],
-				error=(float(table['error']) if scalar_error else got[:, 2].contiguous()), mags=[], maghists=[], magnames=[])
-			return out, got[:, -1].cpu().numpy().astype(numpy.int64)
-		self.zone_primary, self.primary_gidx = redistribute(self.primary, self.primary_offset, False)
-		self.zone_secondaries, self.sec_gidx = [], []
-		for sl, off in zip(self.secondary_slices, self.sec_offset):
-			t, g = redistribute(sl, off, True)
-			self.zone_secondaries.append(t)
-			self.sec_gidx.append(g)
+			out = []
+			for zl in range(zpr):
+				if zpr > 1:
+					# (arrival order = source rank, then zone, then the source's row order: inside ONE zone the rows are still ascending in
+					# the global index, which is what makes local order = global order)
+					sel = torch.nonzero(got[:, -1] == float(self.rank * zpr + zl)).reshape(-1)
+					part = got.index_select(0, sel)
+				else:
+					part = got
+				g_col = -2 if zpr > 1 else -1
+				t = dict(name=table['name'], ra=part[:, 0].contiguous(), dec=part[:, 1].contiguous(), area=table['area'],
+					error=(float(table['error']) if scalar_error else part[:, 2].contiguous()), mags=[], maghists=[], magnames=[])
+				out.append((t, part[:, g_col].cpu().numpy().astype(numpy.int64)))
+			return out
+		prim = redistribute(self.primary, self.primary_offset, False)
+		secs = [redistribute(sl, off, True) for sl, off in zip(self.secondary_slices, self.sec_offset)]
+		self.zones = []
+		for zl in range(zpr):
+			self.zones.append(dict(primary=prim[zl][0], primary_gidx=prim[zl][1], secondaries=[sc[zl][0] for sc in secs], sec_gidx=[sc[zl][1] for sc in secs],
+				plan=None, cats=None, empty=True, status=None))
+		# (one zone per rank: the names of round 4)
+		self.zone_primary, self.primary_gidx = self.zones[0]['primary'], self.zones[0]['primary_gidx']
+		self.zone_secondaries, self.sec_gidx = self.zones[0]['secondaries'], self.zones[0]['sec_gidx']
 		self._sync()
 		self.setup_seconds = time.perf_counter() - t0
 		self._decide()
@@ -969,33 +1002,77 @@ class ZoneShardedMatch(MagnitudePriors):
 		self.scheme = scheme
 
 	def _build_plan(self):
+		"""per local zone: device catalogues and a settled plan (hook ``_build_zone``)"""
 		import nway_amd
 		from nway_amd import _hip
-		tables = [self.zone_primary] + self.zone_secondaries
-		k = len(tables)
+		k = 1 + len(self.secondary_slices)
 		err = self.match_radius / 60. / 60
 		comp = nway_amd._completeness_vector(self.prior_completeness, k)
 		self.params = _hip.make_params(k, self.scheme, self.match_radius, err, self.dens, self.dens_plus,
 			nway_amd._prior_table(self.dens, self.dens_plus, comp), prob_ratio_secondary=self.prob_ratio_secondary, tuning=self.tuning)
-		self.empty = len(self.zone_primary['ra']) == 0  # (a zone without primaries has no rows)
-		self.cats = [_hip.DeviceCatalogue(t['ra'], t['dec'], t['error'], self.device) for t in tables]  # (tensors as they arrived; a scalar error stays one)
-		if self.empty:
-			self.plan, self.status = None, numpy.zeros(_hip.STATUS_WORDS, dtype=numpy.int64)
+		for z in self.zones:
+			self._build_zone(z)
+		self._streams = None
+		z0 = self.zones[0]
+		self.plan, self.cats, self.empty, self.status = z0['plan'], z0['cats'], all(z['empty'] for z in self.zones), z0['status']
+
+	def _build_zone(self, z):
+		import nway_amd
+		from nway_amd import _hip
+		tables = [z['primary']] + z['secondaries']
+		z['empty'] = len(z['primary']['ra']) == 0  # (a zone without primaries has no rows)
+		z['cats'] = [_hip.DeviceCatalogue(t['ra'], t['dec'], t['error'], self.device) for t in tables]  # (tensors as they arrived; a scalar error stays one)
+		if z['empty']:
+			z['plan'], z['status'] = None, numpy.zeros(_hip.STATUS_WORDS, dtype=numpy.int64)
 			return
-		sizes = [c.n for c in self.cats]
+		sizes = [c.n for c in z['cats']]
 		# (capacities from the densities of the whole job: the zone's share of the sky is not known to the estimate)
 		areas = [t['area'] * max(n, 1) / max(g, 1) for t, n, g in zip(tables, sizes, self.global_sizes)]
 		cap_pairs, cap_rows = nway_amd._estimate_capacities(sizes, areas, self.match_radius, self.scheme, True)
-		self.plan, self.status = _hip.run_plan(sizes, self.params, self.cats, cap_pairs, cap_rows, self.device, lean=True)
+		z['plan'], z['status'] = _hip.run_plan(sizes, type(self.params).from_buffer_copy(self.params), z['cats'], cap_pairs, cap_rows, self.device, lean=True)
 
 	# -- per step ------------------------------------------------------------------------
 	def step(self, cats=None):
-		"""one pass of the hot path over this rank's zone (no collective)"""
-		if not self.empty:
-			self.plan.enqueue(self.cats if cats is None else cats)
+		"""one pass of the hot path over this rank's zone(s) (no collective).  Several zones: one after the other, or -- ``streams`` > 1 --
+		round robin on that many streams, which start behind the work already on the current stream and which the current stream
+		waits for at the end (whatever follows on it sees the finished tables)"""
+		live = [z for z in self.zones if not z['empty']]
+		if len(live) <= 1 or self.nstreams == 1:
+			for z in live:
+				self._step_zone(z, cats if (cats is not None and len(self.zones) == 1) else None, None)
+			return
+		import torch
+		if self._streams is None:
+			self._streams = [torch.cuda.Stream(device=self.device) for _ in range(min(self.nstreams, len(live)))]
+		cur = torch.cuda.current_stream(self.device)
+		for st in self._streams:
+			st.wait_stream(cur)
+		for i, z in enumerate(live):
+			self._step_zone(z, None, self._streams[i % len(self._streams)])
+		for st in self._streams:
+			cur.wait_stream(st)
+
+	def _step_zone(self, z, cats, stream):
+		if stream is None:
+			z['plan'].enqueue(z['cats'] if cats is None else cats)
+		else:
+			z['plan'].enqueue(z['cats'], stream=ctypes_stream(stream))
+
+	def _zone_status(self, z):
+		return z['status'] if z['plan'] is None else z['plan'].read_status()
 
 	def read_status(self):
-		return self.status if self.plan is None else self.plan.read_status()
+		"""the status words of the rank's pass; several zones: rows and counters summed, flags or'ed"""
+		from nway_amd import _hip
+		sts = [numpy.asarray(self._zone_status(z)) for z in self.zones]
+		if len(sts) == 1:
+			return sts[0]
+		out = numpy.sum(sts, axis=0)
+		flags = 0
+		for st in sts:
+			flags |= int(st[_hip.ST_FLAGS])
+		out[_hip.ST_FLAGS] = flags
+		return out
 
 	def local_rows(self):
 		from nway_amd import _hip
@@ -1010,45 +1087,69 @@ class ZoneShardedMatch(MagnitudePriors):
 		_dist().all_reduce(t, group=self.group)
 		return int(t.item())
 
+	def close(self):
+		for z in self.zones:
+			if z.get('plan') is not None:
+				z['plan'].close()
+				z['plan'] = None
+		self.plan = None
+
 	def pass_bytes(self, rows):
-		"""algorithmic bytes of this rank's pass: the primaries and secondaries of its zone read once + its rows"""
-		tables = [self.zone_primary] + self.zone_secondaries
-		k = len(tables)
-		b = sum(len(t['ra']) * (16.0 + (8.0 if hasattr(t['error'], 'shape') and len(t['error'].shape) > 0 else 0.0)) for t in tables)
+		"""algorithmic bytes of this rank's pass: the primaries and secondaries of its zone(s) read once + its rows"""
+		k = 1 + len(self.secondary_slices)
+		b = 0.0
+		for z in self.zones:
+			for t in [z['primary']] + z['secondaries']:
+				b += len(t['ra']) * (16.0 + (8.0 if hasattr(t['error'], 'shape') and len(t['error'].shape) > 0 else 0.0))
 		return b + (4 * k + 8 * (k * (k - 1) // 2) + 8 + 1 + 8 * 5 + 1) * rows
 
-	def _local_columns(self):
-		"""the rows of this rank's zone as host columns, LOCAL indices"""
+	def _zone_columns(self, z):
+		"""the rows of one zone as host columns, indices LOCAL to the zone"""
 		from nway_amd import _hip
 		names = [self.primary['name']] + [s['name'] for s in self.secondary_slices]
-		if self.plan is None:
+		if z['plan'] is None:
 			t = dict((nme, numpy.zeros(0, dtype=numpy.int64)) for nme in names + ['ncat', 'match_flag'])
 			for i, j in _hip.pair_columns(len(names)):
 				t['Separation_%s_%s' % (names[i], names[j])] = numpy.zeros(0)
 			for dst in ('Separation_max', 'dist_bayesfactor_uncorrected', 'dist_bayesfactor', 'dist_post', 'p_single', 'prob_has_match', 'prob_this_match'):
 				t[dst] = numpy.zeros(0)
 			return t
-		m = int(self.plan.read_status()[_hip.ST_ROWS])
+		plan = z['plan']
+		m = int(plan.read_status()[_hip.ST_ROWS])
 		t = {}
 		for c, nme in enumerate(names):
-			t[nme] = _hip.to_host(self.plan.cols['idx'][c][:m]).astype(numpy.int64)
+			t[nme] = _hip.to_host(plan.cols['idx'][c][:m]).astype(numpy.int64)
 		for p, (i, j) in enumerate(_hip.pair_columns(len(names))):
-			t['Separation_%s_%s' % (names[i], names[j])] = _hip.to_host(self.plan.cols['sep'][p][:m])
+			t['Separation_%s_%s' % (names[i], names[j])] = _hip.to_host(plan.cols['sep'][p][:m])
 		for src, dst in (('sep_max', 'Separation_max'), ('log_bf', 'dist_bayesfactor_uncorrected'), ('log_bf_corrected', 'dist_bayesfactor'),
 				('dist_post', 'dist_post'), ('p_single', 'p_single'), ('p_any', 'prob_has_match'), ('p_i', 'prob_this_match')):
-			t[dst] = _hip.to_host(self.plan.cols[src][:m])
-		t['ncat'] = _hip.to_host(self.plan.cols['ncat'][:m]).astype(numpy.int64)
-		t['match_flag'] = _hip.to_host(self.plan.cols['match_flag'][:m]).astype(numpy.int64)
+			t[dst] = _hip.to_host(plan.cols[src][:m])
+		t['ncat'] = _hip.to_host(plan.cols['ncat'][:m]).astype(numpy.int64)
+		t['match_flag'] = _hip.to_host(plan.cols['match_flag'][:m]).astype(numpy.int64)
 		return t
 
+	def _local_columns(self):
+		"""(one zone per rank, the hook of round 4) the rows of this rank's zone, LOCAL indices"""
+		return self._zone_columns(self.zones[0])
+
 	def local_table(self):
-		"""this rank's rows as host columns, GLOBAL indices throughout (ascending in the primary)"""
-		t = dict(self._local_columns())
+		"""this rank's rows as host columns, GLOBAL indices throughout, ascending in the primary (several zones: their tables
+		concatenated and sorted stably by primary -- a primary lives in one zone)"""
 		names = [self.primary['name']] + [s['name'] for s in self.secondary_slices]
-		for nme, g in zip(names, [self.primary_gidx] + self.sec_gidx):
-			col = numpy.asarray(t[nme], dtype=numpy.int64)
-			t[nme] = numpy.where(col >= 0, g[numpy.maximum(col, 0)], -1) if len(g) else col
-		return t
+		parts = []
+		for zi, z in enumerate(self.zones):
+			t = dict(self._local_columns() if len(self.zones) == 1 else self._zone_columns(z))
+			for nme, g in zip(names, [z['primary_gidx']] + z['sec_gidx']):
+				col = numpy.asarray(t[nme], dtype=numpy.int64)
+				t[nme] = numpy.where(col >= 0, g[numpy.maximum(col, 0)], -1) if len(g) else col
+			parts.append(t)
+		if len(parts) == 1:
+			return parts[0]
+		fullest = max(parts, key=lambda t: len(t[names[0]]))
+		live = [t for t in parts if len(t[names[0]]) > 0] or [fullest]
+		out = dict((key, numpy.concatenate([numpy.asarray(t[key]) for t in live])) for key in fullest if not key.startswith('_'))
+		order = numpy.argsort(out[names[0]], kind='stable')
+		return dict((key, col[order]) for key, col in out.items())
 
 	def gather_table(self, dst=0):
 		"""global table on rank ``dst``: the ranks' tables concatenated and sorted (stably) by primary; None elsewhere"""

@@ -160,17 +160,16 @@ class OracleZoneShardedMatch(NumpyMagnitudeHooks, distributed.ZoneShardedMatch):
 		pass
 
 	def _build_plan(self):
-		self.empty = len(self.zone_primary['ra']) == 0
+		for z in self.zones:
+			z['empty'] = len(z['primary']['ra']) == 0
+			z['table'] = None
+		self._streams = None
+		self.empty = all(z['empty'] for z in self.zones)
 		self.table = None
 
-	def step(self):
+	def _step_zone(self, z, cats, stream):
 		import nway_oracle as orc
-		names = [self.primary['name']] + [s['name'] for s in self.secondary_slices]
-		if self.empty:
-			t = dict((n, np.zeros(0, dtype=np.int64)) for n in names + ['ncat', 'match_flag'])
-			self.table = t
-			return t
-		tables = [self.zone_primary] + self.zone_secondaries
+		tables = [z['primary']] + z['secondaries']
 		tables = [dict(t, ra=np.asarray(t['ra']), dec=np.asarray(t['dec']), error=(np.broadcast_to(np.asarray(t['error'], dtype=float), np.shape(t['ra'])))) for t in tables]
 		for c in range(1, len(tables)):
 			if len(tables[c]['ra']) == 0:
@@ -178,12 +177,22 @@ class OracleZoneShardedMatch(NumpyMagnitudeHooks, distributed.ZoneShardedMatch):
 				# one source on the far side of the sky stands in; densities and scheme are the whole job's, handed in below)
 				p0 = tables[0]
 				tables[c] = dict(tables[c], ra=np.array([(np.nanmean(p0['ra']) + 180.0) % 360.0]), dec=np.array([-np.nanmean(p0['dec'])]), error=np.array([1.0]))
-		self.table = orc.nway_match(tables, self.match_radius, self.prior_completeness, prob_ratio_secondary=self.prob_ratio_secondary,
+		z['table'] = orc.nway_match(tables, self.match_radius, self.prior_completeness, prob_ratio_secondary=self.prob_ratio_secondary,
 			densities=(self.dens, self.dens_plus), scheme=self.scheme)
+
+	def step(self):
+		for z in self.zones:
+			if not z['empty']:
+				self._step_zone(z, None, None)
+		self.table = self.zones[0].get('table')
 		return self.table
 
-	def local_rows(self):
-		return len(self.table['ncat'])
+	def _empty_table(self):
+		names = [self.primary['name']] + [s['name'] for s in self.secondary_slices]
+		return dict((n, np.zeros(0, dtype=np.int64)) for n in names + ['ncat', 'match_flag'])
 
-	def _local_columns(self):
-		return dict(self.table)
+	def local_rows(self):
+		return sum(len(z['table']['ncat']) for z in self.zones if not z['empty'])
+
+	def _zone_columns(self, z):
+		return dict(z['table']) if not z['empty'] else self._empty_table()

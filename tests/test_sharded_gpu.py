@@ -417,3 +417,45 @@ def test_sharded_magnitude_priors_on_device(tmp_path, mode):
 	for b in ('bias_OPT_R', 'bias_OPT_I', 'bias_IRAC_CH1'):
 		np.testing.assert_allclose(np.asarray(t[b])[rows], g['m3_sub_' + b], rtol=RTOL, err_msg=b)
 		np.testing.assert_allclose(np.sum(t[b]), g['m3_sum_' + b][0], rtol=1e-7, err_msg=b)
+
+
+def local_zone_worker(rank, world, port, outfile, k, flat, zpr, streams):
+	os.environ['MASTER_ADDR'] = '127.0.0.1'
+	os.environ['MASTER_PORT'] = str(port)
+	os.environ['HSA_ENABLE_IPC_MODE_LEGACY'] = '0'
+	dist.init_process_group('gloo', rank=rank, world_size=world)
+	try:
+		sys.path.insert(0, ROOT)
+		from nway_amd import distributed
+		tabs = catalogues(k, flat)
+		dev = torch.device('cuda', 0)
+		torch.cuda.set_device(dev)
+		bounds = [distributed.shard_bounds(len(t['ra']), world) for t in tabs]
+		parts = [dict(t, ra=t['ra'][b[rank]:b[rank + 1]], dec=t['dec'][b[rank]:b[rank + 1]], error=t['error'][b[rank]:b[rank + 1]]) for t, b in zip(tabs, bounds)]
+		zm = distributed.ZoneShardedMatch(parts[0], parts[1:], 10., 0.9, device=dev, zones_per_rank=zpr, streams=streams)
+		assert len(zm.zones) == zpr and len(zm.edges) == world * zpr - 1
+		for _ in range(3):
+			zm.step()
+		total = zm.total_rows()
+		table = zm.gather_table(dst=0)
+		if rank == 0:
+			np.savez(outfile, total=total, zone_rows=zm.local_rows(), **table)
+		zm.close()
+	finally:
+		dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world,k,flat,zpr,streams', [(1, 2, False, 4, 1), (1, 2, False, 4, 2), (1, 3, True, 3, 3), (2, 3, False, 2, 2)])
+def test_several_zones_per_rank_on_device(tmp_path, world, k, flat, zpr, streams):
+	"""several declination zones per rank (ZoneShardedMatch(zones_per_rank=, streams=), round 5): a rank runs its zones one after the other, or
+	round robin on several HIP streams -- down to ONE rank whose zones keep each cell table inside the LDS: the table equals the
+	single-GPU table of the whole job bit for bit"""
+	import nway_amd as nw
+	outfile = str(tmp_path / 'zones.npz')
+	mp.spawn(local_zone_worker, args=(world, free_port(), outfile, k, flat, zpr, streams), nprocs=world, join=True)
+	got = np.load(outfile)
+	tabs = catalogues(k, flat)
+	want = nw.nway_match(tabs, 10., 0.9, logger=nw.NullOutputLogger())
+	assert int(got['total']) == len(want) > len(tabs[0]['ra'])
+	for key in want.columns:
+		np.testing.assert_array_equal(got[key], want[key].values, err_msg=key)

@@ -1,0 +1,51 @@
+"""ONE GPU, several declination zones (ZoneShardedMatch(zones_per_rank=Z, streams=S)): time per pass of the fixed-size jobs
+BASELINE names against the same job as one zone.  Set-up (the one-time bucketing of the catalogues by zone) is outside the pass,
+as the set-up exchanges of the multi-GPU modes are.
+
+    python tools/local_zone_costs.py [c3s|c4s|c5] > profiles/local_zone_costs_r05.md      (on the GPU box)
+"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+import bench
+from nway_amd import distributed, _hip
+
+dev = torch.device('cuda', 0)
+torch.cuda.set_device(dev)
+jobs = dict(c3s=([100000, 10000000], 5.0, [(1, 1), (2, 1), (2, 2), (3, 3), (4, 2)]),
+	c4s=([100000, 1000000, 1000000], 10.0, [(1, 1), (2, 2), (3, 3)]),
+	c5=([500000, 100000000], 5.0, [(1, 1), (4, 1), (5, 1), (5, 2), (5, 3), (6, 3), (8, 2), (8, 3), (8, 4)]))
+which = sys.argv[1:] or ['c3s', 'c4s', 'c5']
+print('| job | zones x streams | us per pass | rows | paths of the zones | factor against one zone |')
+print('|---|---|---|---|---|---|')
+for name in which:
+	sizes, radius, grid = jobs[name]
+	tabs = list(bench.make_workload(sizes[0], sizes[1], 78)) if len(sizes) == 2 else bench.make_workload3(sizes[0], sizes[1], sizes[2], 78)
+	base = None
+	for zpr, streams in grid:
+		eng = distributed.ZoneShardedMatch(tabs[0], tabs[1:], radius, 0.9, dev, zones_per_rank=zpr, streams=streams)
+		for _ in range(30):
+			eng.step()
+		torch.cuda.synchronize(dev)
+		steps = 60 if name != 'c5' else 20
+		t0 = time.perf_counter()
+		for _ in range(steps):
+			eng.step()
+		torch.cuda.synchronize(dev)
+		us = (time.perf_counter() - t0) * 1e6 / steps
+		st = eng.read_status()
+		assert int(st[_hip.ST_FLAGS]) == 0
+		rows = int(st[_hip.ST_ROWS])
+		base = base or (us, rows)
+		assert rows == base[1], (rows, base)
+		paths = sorted(set('%s/%s' % (z['plan'].description['sweep'], z['plan'].description['tail']) for z in eng.zones if z['plan'] is not None))
+		print('| %s %s | %d x %d | %.1f | %d | %s | %.2f |' % (name, ' x '.join('%g' % n for n in sizes), zpr, streams, us, rows, ', '.join(paths), base[0] / us))
+		sys.stdout.flush()
+		eng.close()
+		del eng
+		torch.cuda.empty_cache()
