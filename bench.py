@@ -478,9 +478,11 @@ def single_gpu_jobs(args, device, names, budget_s=240.0):
 			cats = [_hip.DeviceCatalogue(t['ra'], t['dec'], np.asarray(t['error'], dtype=float), device) for t in tabs]
 			cap_pairs, cap_rows = nway_amd._estimate_capacities([c.n for c in cats], [SKY_AREA] * k, radius, scheme, True)
 			plan, st = _hip.run_plan([c.n for c in cats], params, cats, cap_pairs, cap_rows, device, lean=True)
-			for _ in range(warm):
-				plan.enqueue(cats)
-			torch.cuda.synchronize(device)
+			t0 = time.perf_counter()
+			while time.perf_counter() - t0 < 0.03:  # (at least 30 ms of passes first: the clocks of an idle GPU take ~10 ms to come up)
+				for _ in range(warm):
+					plan.enqueue(cats)
+				torch.cuda.synchronize(device)
 			t0 = time.perf_counter()
 			for _ in range(steps):
 				plan.enqueue(cats)
@@ -499,11 +501,12 @@ def single_gpu_jobs(args, device, names, budget_s=240.0):
 				cats = None
 				torch.cuda.empty_cache()
 				from nway_amd import distributed
-				eng = distributed.ZoneShardedMatch(tabs[0], tabs[1:], radius, args.completeness, device, zones_per_rank=8, streams=2)
+				eng = distributed.ZoneShardedMatch(tabs[0], tabs[1:], radius, args.completeness, device, zones_per_rank=8, streams=2, local_only=True)
 				try:
-					for _ in range(warm):
+					t0 = time.perf_counter()
+					while time.perf_counter() - t0 < 0.03:  # (24 short launches per pass: the clocks of an idle GPU take ~10 ms to come up)
 						eng.step()
-					torch.cuda.synchronize(device)
+						torch.cuda.synchronize(device)
 					t0 = time.perf_counter()
 					for _ in range(steps):
 						eng.step()

@@ -788,6 +788,8 @@ def exchange_rows(rows, send_counts, group=None):
 	tensors (device tensors -- ranks sharing one GPU in the functional tests -- go through the host)."""
 	import torch
 	dist = _dist()
+	if len(send_counts) == 1:  # (one destination: this process alone, whatever process group is up)
+		return rows
 	rank, world = world_info(group)
 	if world == 1:
 		return rows
@@ -831,8 +833,10 @@ class ZoneShardedMatch(MagnitudePriors):
 	ZONE_BINS = 1 << 16
 
 	def __init__(self, primary, secondaries, match_radius, prior_completeness, device, group=None,
-			prob_ratio_secondary=0.5, tuning=None, comm=None, zones_per_rank=1, streams=1):
-		"""zones_per_rank: every rank holds this many declination zones and runs them one after the other in a step (round 5).
+			prob_ratio_secondary=0.5, tuning=None, comm=None, zones_per_rank=1, streams=1, local_only=False):
+		"""local_only: this process alone, whatever process group is up (the catalogues handed in are the WHOLE catalogues; no collective
+		is issued) -- ``bench.py`` measures the one-GPU reference of a job on rank 0 that way while the other ranks wait.
+		zones_per_rank: every rank holds this many declination zones and runs them one after the other in a step (round 5).
 		A zone is an ordinary match of its own: several small zones keep the cell table of each within the LDS of a sweep
 		workgroup where the one big zone would need the large-table sweep (5e5 x 1e8 on ONE GPU: 729 us as one zone) -- and with
 		``streams`` > 1 the zones of a step are enqueued round robin on that many HIP streams, so that the latency-bound ends of
@@ -853,7 +857,7 @@ class ZoneShardedMatch(MagnitudePriors):
 		self.device = device
 		self.group = group
 		self.tuning = tuning
-		self.rank, self.world = world_info(group)
+		self.rank, self.world = (0, 1) if local_only else world_info(group)
 		self.zones_per_rank = max(1, int(zones_per_rank))
 		self.nstreams = max(1, int(streams))
 		self.plan = None
