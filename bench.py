@@ -681,7 +681,8 @@ def main():
 		# pipelines (workspace + output table + HIP stream each) so that the latency-bound stages of
 		# one pass overlap the HBM-bound sweep of another
 		plans = [plan] + [_hip.MatchPlan(sizes, params, plan.cap_pairs, plan.cap_rows, device, lean=True) for _ in range(args.streams - 1)]
-		streams = [torch.cuda.Stream(device=device) for _ in plans] if len(plans) > 1 else [None]
+		from nway_amd import distributed as _ds
+		streams = _ds.side_streams(device, len(plans)) if len(plans) > 1 else [None]
 		counter = [0]
 
 		def step():
@@ -848,7 +849,8 @@ def main():
 			first = plan
 			npipes = max(2, int(args.two_pipelines))
 			more = [_hip.MatchPlan(sizes, params2, plan.cap_pairs, plan.cap_rows, device, lean=True) for _ in range(npipes - 2)]
-			pair, lanes = [first, second] + more, [torch.cuda.Stream(device=device) for _ in range(npipes)]
+			from nway_amd import distributed as _d
+			pair, lanes = [first, second] + more, _d.side_streams(device, npipes)  # (the package's own side streams: see there)
 
 			def two(n):
 				for j in range(n):

@@ -29,6 +29,23 @@ def _dist():
 	return dist
 
 
+_side_streams = {}
+
+
+def side_streams(device, n):
+	"""``n`` HIP streams beside the current one, made once per device and handed out again: the runtime multiplexes streams onto a
+	handful of hardware queues (four by default), and every further stream a process creates may land on the queue of one it is
+	meant to run beside -- measured: the eight zones of a 5e5 x 1e8 job on two streams took 543 us per pass in a fresh process and
+	684 us behind two other streams made earlier (bench.py's two_pipelines leg) -- so everything in this package that wants side
+	streams takes them from here"""
+	import torch
+	key = str(torch.device(device))
+	have = _side_streams.setdefault(key, [])
+	while len(have) < n:
+		have.append(torch.cuda.Stream(device=device))
+	return have[:n]
+
+
 def ctypes_stream(stream):
 	"""a torch stream as the ``void*`` the C ABI takes"""
 	import ctypes
@@ -1047,7 +1064,7 @@ class ZoneShardedMatch(MagnitudePriors):
 			return
 		import torch
 		if self._streams is None:
-			self._streams = [torch.cuda.Stream(device=self.device) for _ in range(min(self.nstreams, len(live)))]
+			self._streams = side_streams(self.device, min(self.nstreams, len(live)))
 		cur = torch.cuda.current_stream(self.device)
 		for st in self._streams:
 			st.wait_stream(cur)
