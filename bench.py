@@ -349,7 +349,7 @@ def extra_configs(args, world, rank, device, dist, backend):
 	comms = ['torch'] + (['rccl'] if backend == 'nccl' else [])
 	steps, warm = min(args.steps, 20), min(max(args.warmup, 2), 5)
 	records = []
-	budget_s = float(os.environ.get('NWAY_BENCH_EXTRA_BUDGET', '420'))  # the whole block is skipped job by job once this is spent
+	budget_s = float(os.environ.get('NWAY_BENCH_EXTRA_BUDGET', '300'))  # the whole block is skipped job by job once this is spent
 	t_start = time.perf_counter()
 
 	def agreed(ok):

@@ -119,3 +119,24 @@ def test_cli_writes_what_the_script_writes(tag, tmp_path, monkeypatch):
 		got = np.loadtxt(name)
 		assert open(name).readline() == text.splitlines(True)[0]
 		np.testing.assert_allclose(got, want, rtol=0, atol=1.001e-5, err_msg=name)
+
+
+def test_nway_py_as_a_program(tmp_path):
+	"""``python nway.py ...`` itself (the drop-in's entry script, a process of its own) on the reference's test catalogues: the table the
+	reference's script wrote, and NWAYCMD = the command line as typed (nway.py:644)"""
+	import subprocess
+	import sys
+	from goldenutil import ROOT
+	from nway_amd import _fits
+	meta, g = META['ell2'], golden('script_cli')
+	stage_inputs('ell2', tmp_path)
+	script = os.path.join(ROOT, 'nway.py')
+	res = subprocess.run([sys.executable, script] + list(meta['argv']), cwd=str(tmp_path), stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, timeout=600)
+	assert res.returncode == 0, res.stderr[-2000:]
+	assert 'matches after filtering by search radius' in res.stdout and 'creating output FITS file' in res.stdout
+	out = _fits.read_table(str(tmp_path / 'ell2.fits'))
+	assert out.names == meta['columns'] and len(out.data) == meta['nrows']
+	np.testing.assert_array_equal(out.data['match_flag'], g['ell2/match_flag'])
+	compare_float(out.data['p_i'], g['ell2/p_i'], 'p_i')
+	head = _fits.read_header(str(tmp_path / 'ell2.fits'), 0)
+	assert head['NWAYCMD'] == ' '.join([script] + list(meta['argv']))
