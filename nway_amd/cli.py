@@ -8,8 +8,9 @@ unrelated-association correction is the working one (nway.py:366-423), the auto-
 selection indexes its weights by the selected rows (nway.py:471).
 
 The script's numerics are reproduced as well (``f32_roundtrip``: its separations pass through a
-float32 FITS column before log_bf squares them; pinned by tests/golden/f32.npz,
-magscript.npz and the script variants of fuzz.npz / kway.npz / sparse.npz).
+float32 FITS column before log_bf squares them).  Pinned to the reference's script ITSELF: tests/golden/script_cli.npz /
+.json hold the tables /root/reference/nway.py wrote for eleven command lines (tests/golden/make_script_golden.py executes it under an
+I/O-only stand-in for astropy.io.fits), tests/test_cli_script_golden.py compares this module's output files with them.
 
 Asymmetric / elliptical error columns (``:ra_err:dec_err``, ``:major:minor:angle``) use the
 device pipeline for the candidates and nway_amd/elliptical.py (device kernels for the offsets
