@@ -97,9 +97,8 @@ def apply_magnitude_biasing(match_tables, table, res, mag_include_radius, mag_ex
 			if store_mag_hists:
 				magnitudeweights.plot_fit(bins, hist_sel, hist_all, func, mag)
 			# per-row lookup on the device: weight = log10(func(mag[idx])), undefined -> 0
-			d_mag = _hip.to_device(numpy.where(numpy.isfinite(mag_all), mag_all, numpy.nan), device)
-			d_edges = _hip.to_device(func.edges, device)
-			d_ratio = _hip.to_device(func.values, device)
+			# (one transfer for the three: _hip.upload_columns)
+			d_mag, d_edges, d_ratio = _hip.upload_columns([numpy.where(numpy.isfinite(mag_all), mag_all, numpy.nan), func.edges, func.values], device)
 			d_bias = t.empty(nrows, dtype=t.float64, device=device)
 			_hip.check(lib.nwayhip_bias_lookup(nrows, _hip.ptr(res.column('idx', i)), _hip.ptr(d_mag), len(func.edges),
 				_hip.ptr(d_edges), _hip.ptr(d_ratio), _hip.ptr(total), _hip.ptr(d_bias), _hip.current_stream_ptr(device)))
