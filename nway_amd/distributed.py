@@ -984,8 +984,13 @@ class ZoneShardedMatch(MagnitudePriors):
 				else:
 					part = got
 				g_col = -2 if zpr > 1 else -1
-				t = dict(name=table['name'], ra=part[:, 0].contiguous(), dec=part[:, 1].contiguous(), area=table['area'],
-					error=(float(table['error']) if scalar_error else part[:, 2].contiguous()), mags=[], maghists=[], magnames=[])
+				def column(i):
+					# (a column of a one-row table is already "contiguous" where it lies inside the packed row: 8-byte aligned only --
+					# found by the local-zones soak, where a zone may hold one source of a catalogue; the library wants 16)
+					c = part[:, i].contiguous()
+					return c.clone() if c.data_ptr() % 16 else c
+				t = dict(name=table['name'], ra=column(0), dec=column(1), area=table['area'],
+					error=(float(table['error']) if scalar_error else column(2)), mags=[], maghists=[], magnames=[])
 				out.append((t, part[:, g_col].cpu().numpy().astype(numpy.int64)))
 			return out
 		prim = redistribute(self.primary, self.primary_offset, False)

@@ -40,6 +40,8 @@ class OneZone(distributed.ZoneShardedMatch):
 		self.plan = None
 		self.primary_sizes = [len(whole[0]['ra'])]
 		self.sec_global = [len(t['ra']) for t in whole[1:]]
+		self.zones_per_rank, self.nstreams = 1, 1
+		self.zones = [dict(primary=zone_tables[0], primary_gidx=gidx[0], secondaries=zone_tables[1:], sec_gidx=gidx[1:], plan=None, cats=None, empty=True, status=None)]
 		self._decide()
 		self.scheme = scheme  # (of the whole job)
 		self._build_plan()
@@ -53,8 +55,7 @@ def whole_table(tables, radius, completeness):
 	z = OneZone(tables, ident, tables, radius, completeness, scheme)
 	z.step()
 	t = z.gather_table()
-	if z.plan is not None:
-		z.plan.close()
+	z.close()
 	return t, scheme
 
 
@@ -69,6 +70,18 @@ for seed in range(lo, hi):
 	comp = float(rng.choice([1.0, 0.9, 0.5]))
 	try:
 		want, scheme = whole_table(tabs, radius, comp)
+		if len(sys.argv) > 3 and sys.argv[3] == 'local':
+			# round 5: ONE rank, several zones, cut and run by the engine itself (zones_per_rank, streams)
+			zpr, streams = int(rng.choice([2, 3, 5, 8])), int(rng.choice([1, 2, 3]))
+			eng = distributed.ZoneShardedMatch(tabs[0], tabs[1:], radius, comp, dev, zones_per_rank=zpr, streams=streams, local_only=True)
+			for _ in range(2):
+				eng.step()
+			got = eng.gather_table()
+			eng.close()
+			for key in want:
+				np.testing.assert_array_equal(got[key], want[key], err_msg='%s (zones %d, streams %d)' % (key, zpr, streams))
+			rows += len(want[tabs[0]['name']])
+			continue
 		world = int(rng.choice([2, 3, 5]))
 		big = 1 + int(np.argmax([len(t['ra']) for t in tabs[1:]]))
 		dec = np.asarray(tabs[big]['dec'], dtype=float)
@@ -91,8 +104,7 @@ for seed in range(lo, hi):
 			eng = OneZone(zt, gidx, tabs, radius, comp, scheme)
 			eng.step()
 			parts.append(eng.local_table())
-			if eng.plan is not None:
-				eng.plan.close()
+			eng.close()
 		pname = tabs[0]['name']
 		fullest = max(parts, key=lambda g: len(g[pname]))
 		got = dict((key, np.concatenate([np.asarray(g[key]) for g in parts if len(g[pname]) > 0] or [np.asarray(fullest[key])[:0]])) for key in fullest)
