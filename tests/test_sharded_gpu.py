@@ -459,3 +459,28 @@ def test_several_zones_per_rank_on_device(tmp_path, world, k, flat, zpr, streams
 	assert int(got['total']) == len(want) > len(tabs[0]['ra'])
 	for key in want.columns:
 		np.testing.assert_array_equal(got[key], want[key].values, err_msg=key)
+
+
+def test_zones_holding_one_source_or_none():
+	"""eight zones over catalogues of a few dozen sources: zones with ONE source of a catalogue (its columns must not be views into the
+	packed row: the library wants 16-byte aligned columns -- found by tools/dev/soak_zones.py in round 5) and with none"""
+	import nway_amd as nw
+	from nway_amd import distributed
+	rng = np.random.RandomState(3)
+	sky = lambda n: (rng.uniform(0, 360, n), np.degrees(np.arcsin(rng.uniform(-1, 1, n))))
+	a = cat('A', *sky(40), rng.uniform(0.5, 2, 40), 41252.96)
+	b = cat('B', *sky(13), 0.3 * np.ones(13), 41252.96)
+	c = cat('C', *sky(300), 0.5 * np.ones(300), 41252.96)
+	b['ra'][:8], b['dec'][:8] = a['ra'][:8] + 1e-4, a['dec'][:8]
+	c['ra'][:20], c['dec'][:20] = a['ra'][:20], np.clip(a['dec'][:20] + 2e-4, -90, 90)
+	dev = torch.device('cuda', 0)
+	want = nw.nway_match([a, b, c], 10., 0.9, logger=nw.NullOutputLogger())
+	for zpr, streams in ((8, 1), (8, 3), (5, 2)):
+		eng = distributed.ZoneShardedMatch(a, [b, c], 10., 0.9, dev, zones_per_rank=zpr, streams=streams, local_only=True)
+		assert min(len(z['secondaries'][0]['ra']) for z in eng.zones) <= 1
+		eng.step()
+		got = eng.gather_table()
+		eng.close()
+		assert len(got['ncat']) == len(want) > 40
+		for key in want.columns:
+			np.testing.assert_array_equal(got[key], want[key].values, err_msg=key)
