@@ -77,7 +77,8 @@ def run_script(argv, quiet=True):
 		with contextlib.redirect_stdout(buf), contextlib.redirect_stderr(err):
 			g = runpy.run_path(os.path.join(REFERENCE, 'nway.py'), run_name='__main__')
 	except BaseException:
-		sys.stderr.write(buf.getvalue()[-3000:])
+		if not os.environ.get('NWAY_SCRIPT_QUIET_ERRORS'):
+			sys.stderr.write(buf.getvalue()[-3000:])
 		raise
 	finally:
 		sys.argv = old
@@ -396,8 +397,58 @@ def gen_cli():
 	shutil.copyfile(os.path.join(REFERENCE, 'doc', 'COSMOS_XMM.fits'), os.path.join(dest, 'COSMOS_XMM.fits'))
 
 
+def error_inputs(write):
+	"""small defective catalogues for the script's input checks; ``write(filename, extname, skyarea or None, columns)``"""
+	rng = np.random.RandomState(8)
+	n = 30
+	ra, dec = 150 + rng.uniform(0, 0.01, n), 2 + rng.uniform(0, 0.01, n)
+	cols = [('ID', 'J', np.arange(n)), ('RA', 'D', ra), ('DEC', 'D', dec), ('pos_err', 'D', np.full(n, 0.5)), ('MAG', 'D', rng.normal(20, 1, n))]
+	write('good_a.fits', 'A', 0.01, cols)
+	write('good_b.fits', 'B', 0.01, [('ID', 'J', np.arange(n)), ('RA', 'D', ra + 1e-4), ('DEC', 'D', dec), ('MAG', 'D', rng.normal(22, 1, n))])
+	write('noarea.fits', 'NA', None, cols)
+	write('dupid.fits', 'DUP', 0.01, [('ID', 'J', np.zeros(n, dtype=int))] + cols[1:])
+	write('far.fits', 'FAR', 0.01, [('ID', 'J', np.arange(n)), ('RA', 'D', ra + 1.0), ('DEC', 'D', dec + 1.0)])
+
+
+ERROR_CASES = [
+	('no_skyarea', ['--radius', '5', 'noarea.fits', ':pos_err', 'good_b.fits', '0.3', '--out', 'o.fits']),
+	('completeness_count', ['--radius', '5', 'good_a.fits', ':pos_err', 'good_b.fits', '0.3', '--out', 'o.fits', '--prior-completeness', '0.9:0.8']),
+	('mag_unknown_table', ['--radius', '5', 'good_a.fits', ':pos_err', 'good_b.fits', '0.3', '--out', 'o.fits', '--mag', 'C:MAG', 'auto']),
+	('mag_unknown_column', ['--radius', '5', 'good_a.fits', ':pos_err', 'good_b.fits', '0.3', '--out', 'o.fits', '--mag', 'B:NOPE', 'auto']),
+	('error_column_missing', ['--radius', '5', 'good_a.fits', ':nocol', 'good_b.fits', '0.3', '--out', 'o.fits']),
+	('too_many_error_columns', ['--radius', '5', 'good_a.fits', ':a:b:c:d', 'good_b.fits', '0.3', '--out', 'o.fits']),
+	('duplicate_ids', ['--radius', '5', 'dupid.fits', ':pos_err', 'good_b.fits', '0.3', '--out', 'o.fits']),
+	('minprob_zero', ['--radius', '5', 'good_a.fits', ':pos_err', 'good_b.fits', '0.3', '--out', 'o.fits', '--mag-auto-minprob', '0']),
+]
+
+
+def gen_errors():
+	"""how the script refuses defective input: the exception type and its message, for the product's command line to repeat"""
+	def write(filename, extname, skyarea, columns):
+		hdu = fits_standin.BinTableHDU.from_columns(fits_standin.ColDefs([fits_standin.Column(name=n, format=t, array=a) for n, t, a in columns]))
+		hdu.header['EXTNAME'] = extname
+		if skyarea is not None:
+			hdu.header['SKYAREA'] = float(skyarea)
+		fits_standin.HDUList([fits_standin.PrimaryHDU(), hdu]).writeto(filename, overwrite=True)
+	error_inputs(write)
+	out = {}
+	for tag, argv in ERROR_CASES:
+		try:
+			run_script(argv)
+			raise RuntimeError('%s: the script accepted the input' % tag)
+		except RuntimeError:
+			raise
+		except BaseException as e:
+			out[tag] = dict(argv=argv, type=type(e).__name__, message=str(e))
+			print('%-24s %s: %s' % (tag, type(e).__name__, str(e)[:110]))
+	with open(os.path.join(HERE, 'script_errors.json'), 'w') as f:
+		json.dump(out, f, indent=1, sort_keys=True)
+
+
 if __name__ == '__main__':
-	which = sys.argv[1:] or ['cli', 'api']
+	which = sys.argv[1:] or ['cli', 'api', 'errors']
+	if 'errors' in which:
+		gen_errors()
 	if 'cli' in which:
 		gen_cli()
 	if 'api' in which:
