@@ -32,6 +32,10 @@ does is a change of container or of storage type that astropy performs for the s
 
 Independent of nway_amd/_fits.py (the product's reader/writer) on purpose: the fixtures must
 not inherit a reading error of the code they test.
+
+One section at the end is NOT I/O and says so: the few names of ``astropy.coordinates`` /
+``astropy.units`` that ``fastskymatch.dist3d`` uses, for the script runs through the elliptical
+branch (``install(coordinates=True)``).
 """
 import builtins
 import os
@@ -355,16 +359,72 @@ def write_catalogue(filename, extname, skyarea, columns):
 	HDUList([PrimaryHDU(), hdu]).writeto(filename, overwrite=True)
 
 
-def install(healpix=False):
+# ---------------------------------------------------------------------------------------------
+# astropy.coordinates / astropy.units, as far as fastskymatch.dist3d (:50-74) uses them -- the ONE part of this file that is not
+# I/O: the script's elliptical branch calls SkyCoord(ra, dec, frame="icrs", unit="deg"), SkyOffsetFrame(origin=a),
+# transform_to, .lon / .lat, separation, .to(u.degree).value.  The rotation into the offset frame is the restatement of what
+# astropy documents for that frame (oracle/elliptical_oracle.py: offsets -- origin to (0, 0), no roll; pinned by hand-computed
+# known answers, tests/test_elliptical_helpers.py), the separation is the reference's own Vincenty formula (fastskymatch.dist,
+# the expression astropy's angular_separation documents).  What a script run under this stand-in pins is therefore the SCRIPT --
+# its error columns, its float32 trips, its branch logic, its output table -- around these two functions, not astropy itself.
+class _Degrees(object):
+	def __init__(self, value):
+		self.value = np.asarray(value, dtype=float)
+
+	def __sub__(self, other):
+		return _Degrees(self.value - other.value)
+
+	def to(self, unit):
+		assert unit is DEGREE, unit
+		return self
+
+
+class _UnitDegree(object):
+	pass
+
+
+DEGREE = _UnitDegree()
+
+
+class SkyOffsetFrame(object):
+	def __init__(self, origin):
+		self.origin = origin
+
+
+class _OffsetPosition(object):
+	def __init__(self, lon, lat):
+		self.lon, self.lat = _Degrees(lon), _Degrees(lat)
+
+
+class SkyCoord(object):
+	def __init__(self, ra, dec, frame='icrs', unit='deg'):
+		assert frame == 'icrs' and unit == 'deg', (frame, unit)
+		self.ra, self.dec = np.asarray(ra, dtype=float), np.asarray(dec, dtype=float)
+
+	def transform_to(self, frame):
+		sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..', 'oracle'))
+		import elliptical_oracle
+		o = frame.origin
+		# offsets() returns origin minus point in the origin's frame, the origin being (0, 0) there: the point is its negative
+		dlon, dlat = elliptical_oracle.offsets(o.ra, o.dec, self.ra, self.dec)
+		return _OffsetPosition(-dlon, -dlat)
+
+	def separation(self, other):
+		from nwaylib.fastskymatch import dist  # (the reference's; loaded by the time the script gets here)
+		return _Degrees(dist((self.ra, self.dec), (other.ra, other.dec)))
+
+
+def install(healpix=False, coordinates=False):
 	"""register this module as astropy.io.fits, plus the empty astropy / healpy stand-ins the import
-	of nwaylib needs (tests/golden/ref_harness.py explains them)"""
+	of nwaylib needs (tests/golden/ref_harness.py explains them); ``coordinates``: the stand-in above for dist3d"""
 	me = sys.modules[__name__]
 	io = types.ModuleType('astropy.io')
 	io.fits = me
 	units = types.ModuleType('astropy.units')
+	units.degree = DEGREE
 	coords = types.ModuleType('astropy.coordinates')
-	coords.SkyCoord = None
-	coords.SkyOffsetFrame = None
+	coords.SkyCoord = SkyCoord if coordinates else None
+	coords.SkyOffsetFrame = SkyOffsetFrame if coordinates else None
 	top = types.ModuleType('astropy')
 	top.io, top.units, top.coordinates = io, units, coords
 	sys.modules.update({'astropy': top, 'astropy.io': io, 'astropy.io.fits': me, 'astropy.units': units, 'astropy.coordinates': coords})

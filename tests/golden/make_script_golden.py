@@ -55,7 +55,7 @@ sys.path.insert(0, ROOT)
 import fits_standin  # noqa: E402
 
 warnings.simplefilter('ignore')
-fits_standin.install(healpix=True)
+fits_standin.install(healpix=True, coordinates=True)
 import matplotlib  # noqa: E402
 matplotlib.use('Agg')
 
@@ -397,6 +397,47 @@ def gen_cli():
 	shutil.copyfile(os.path.join(REFERENCE, 'doc', 'COSMOS_XMM.fits'), os.path.join(dest, 'COSMOS_XMM.fits'))
 
 
+ELL_CASES = [
+	# the rotated ellipses of tests/golden/ell_flow.npz (three catalogues, ``:major:minor:angle`` each; nway.py:52-66, 303-305, 346-354, 402-411)
+	('rot3', ['--radius', '15', 'X.fits', ':major:minor:angle', 'O.fits', ':major:minor:angle', 'I.fits', ':major:minor:angle',
+		'--prior-completeness', '0.9', '--out', 'rot3.fits']),
+	# two columns = axis-aligned errors in RA and Dec (nway.py:68-77), two catalogues, with a probability cut
+	('asym2', ['--radius', '15', 'X.fits', ':major:minor', 'O.fits', ':major:minor', '--min-prob', '0.01', '--out', 'asym2.fits']),
+	# mixed: a rotated ellipse, a fixed error, one column (nway.py:32-38, 79-88); the unrelated associations ignored
+	('mixed3', ['--radius', '12', 'X.fits', ':major:minor:angle', 'O.fits', '0.8', 'I.fits', ':major', '--prior-completeness', '0.85:0.7',
+		'--ignore-unrelated-associations', '--out', 'mixed3.fits']),
+]
+
+
+def gen_ell():
+	"""the script's branch for elliptical / asymmetric position errors, executed (not transcribed): astropy's coordinate frames inside
+	fastskymatch.dist3d are the stand-in of fits_standin.py (the documented rotation; the reference's own separation formula)"""
+	flow = np.load(os.path.join(HERE, 'ell_flow.npz'))
+	area = float(flow['area'][0])
+	for c, name in enumerate(['X', 'O', 'I']):
+		cols = dict((col, flow['in%d_%s' % (c, col)]) for col in ('ra', 'dec', 'major', 'minor', 'angle'))
+		n = len(cols['ra'])
+		fits_standin.write_catalogue(name + '.fits', name, area, [('ID', 'J', np.arange(n)), ('RA', 'D', cols['ra']), ('DEC', 'D', cols['dec']),
+			('major', 'D', cols['major']), ('minor', 'D', cols['minor']), ('angle', 'D', cols['angle'])])
+	meta, arrays = {}, {}
+	for tag, argv in ELL_CASES:
+		g, log = run_script(argv)
+		table_record(tag + '.fits', meta, arrays, tag, g, full=True)
+		meta[tag]['argv'] = argv
+		print('%-14s %7d rows  %.1f s' % (tag, meta[tag]['nrows'], g['__seconds__']))
+	# the transcription of round 4 (make_golden.py: gen_ellflow) against the script's own run of the same input
+	t = fits_standin.open('rot3.fits')[1].data
+	assert len(t) == len(flow['ncat'])
+	np.testing.assert_array_equal(native(t['ncat']), flow['ncat'])
+	np.testing.assert_array_equal(native(t['match_flag']), flow['match_flag'])
+	for col, key in (('dist_bayesfactor', 'dist_bayesfactor_uncorrected'), ('dist_bayesfactor_corrected', 'dist_bayesfactor'), ('p_i', 'prob_this_match')):
+		np.testing.assert_array_equal(native(t[col]), flow[key].astype(np.float32), err_msg=col)
+	print('rot3: the transcription of ell_flow.npz agrees with the script bit for bit (float32 columns)')
+	save('script_ell', **arrays)
+	with open(os.path.join(HERE, 'script_ell.json'), 'w') as f:
+		json.dump(meta, f, indent=1, sort_keys=True)
+
+
 def error_inputs(write):
 	"""small defective catalogues for the script's input checks; ``write(filename, extname, skyarea or None, columns)``"""
 	rng = np.random.RandomState(8)
@@ -446,7 +487,9 @@ def gen_errors():
 
 
 if __name__ == '__main__':
-	which = sys.argv[1:] or ['cli', 'api', 'errors']
+	which = sys.argv[1:] or ['cli', 'api', 'errors', 'ell']
+	if 'ell' in which:
+		gen_ell()
 	if 'errors' in which:
 		gen_errors()
 	if 'cli' in which:
