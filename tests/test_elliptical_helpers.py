@@ -321,3 +321,41 @@ def test_cli_elliptical_flow_golden(tmp_path, monkeypatch):
 	np.testing.assert_array_equal(np.asarray(d['match_flag'], dtype=np.int64), g['match_flag'])
 	changed = np.flatnonzero(np.asarray(d['dist_bayesfactor_corrected']) != np.asarray(d['dist_bayesfactor']))
 	assert len(changed) > 20 and set(changed) <= set(g['changed_rows'])
+
+
+def _astropyconsistent_inputs():
+	"""the positions of the reference's test_dist_astropyconsistent (tests/fastskymatch_test.py:74-82): 3 998 declinations between 0 and 90,
+	a shift of 1e-5 degrees in right ascension"""
+	dec = np.linspace(0, 90, 4000)[1:-1]
+	ra = np.zeros_like(dec)
+	return ra, dec, ra + 1e-5, dec + 0.0
+
+
+def test_offsets_of_the_oracle_as_the_reference_tests_astropys():
+	"""tests/fastskymatch_test.py:74-106 asserts of astropy's offset frame that the length of (na.lon - nb.lon, na.lat - nb.lat) equals the
+	separation to 7 decimals (degrees); the same assertion on the stand-in's rotation (oracle/elliptical_oracle.py: offsets) with the
+	separation of the oracle's dist -- a property of the reference's own test that the restatement of dist3d has to have"""
+	import os
+	import sys
+	sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'oracle'))
+	import elliptical_oracle as eo
+	import nway_oracle as orc
+	a_ra, a_dec, b_ra, b_dec = _astropyconsistent_inputs()
+	dra, ddec = eo.offsets(a_ra, a_dec, b_ra, b_dec)
+	d = orc.dist((a_ra, a_dec), (b_ra, b_dec))
+	np.testing.assert_array_almost_equal(d, (dra**2 + ddec**2)**0.5, decimal=7)
+	# (and far beyond 7 decimals: at 1e-5 degrees the tangent plane is exact to ~1e-15 relative)
+	np.testing.assert_allclose((dra**2 + ddec**2)**0.5, d, rtol=1e-9)
+	assert (dra < 0).all()  # a minus b, b to the east
+
+
+@pytest.mark.gpu
+def test_offsets_on_the_device_as_the_reference_tests_astropys():
+	"""the same assertion (tests/fastskymatch_test.py:74-106) on nwayhip_offsets and the device's dist"""
+	import nway_amd
+	from nway_amd import elliptical
+	a_ra, a_dec, b_ra, b_dec = _astropyconsistent_inputs()
+	dra, ddec = elliptical.offsets(a_ra, a_dec, b_ra, b_dec)
+	d = nway_amd.fastskymatch.dist((a_ra, a_dec), (b_ra, b_dec))
+	np.testing.assert_array_almost_equal(d, (dra**2 + ddec**2)**0.5, decimal=7)
+	np.testing.assert_allclose((dra**2 + ddec**2)**0.5, d, rtol=1e-9)
