@@ -153,7 +153,6 @@ def measured_ceilings(sec_copies, device, reps=30):
 	"""what this box's memory system gives, measured in this run ('also measure an on-box copy
 	kernel'): the sweep's stream with nothing behind the loads (read only, alternating over the copies of
 	the secondary catalogue so that the Infinity Cache does not serve it), and a device-to-device copy"""
-	import ctypes
 	import torch
 	from nway_amd import _hip
 	lib = _hip.load()

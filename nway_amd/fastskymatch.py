@@ -7,7 +7,6 @@ mirrors argument conventions.  No CPU fallback.
 """
 from __future__ import division, print_function
 
-import ctypes
 
 import numpy
 

@@ -3,7 +3,6 @@ made by executing /root/reference/nway.py on the same defective catalogues: test
 nway_amd/cli.py.  Every one of these checks comes before the match, so no GPU is needed."""
 import json
 import os
-import sys
 
 import numpy as np
 import pytest

@@ -801,7 +801,6 @@ def test_sparse_tails_with_more_rows_than_their_staging_area(nw, k):
 def test_read_probe_sums_both_columns(nw):
 	"""nwayhip_read_probe (bench.py's measured read ceiling): every element of both columns is read exactly once --
 	the per-workgroup partial sums add up to the sum of the columns, for sizes that do not divide into the tiles"""
-	import ctypes
 	import torch
 	from nway_amd import _hip
 	lib = _hip.load()

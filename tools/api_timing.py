@@ -13,7 +13,6 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'tests'))
-import numpy as np
 import torch
 import nway_amd
 from goldenutil import ell_tables, xmm_tables, mag3_tables

@@ -10,7 +10,6 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-import numpy as np
 import torch
 import bench
 from nway_amd import distributed, _hip

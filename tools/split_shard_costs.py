@@ -7,12 +7,10 @@ run delivers), i.e. its time is a slight underestimate.
 
     python tools/split_shard_costs.py [n_primary] [n_secondary] [radius]      (on the GPU box)
 """
-import ctypes
 import os
 import sys
 import time
 
-import numpy as np
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
