@@ -273,16 +273,18 @@ def nway_match(match_tables, match_radius, prior_completeness,
 	cols['dist_bayesfactor_uncorrected'] = res.to_host('log_bf')
 	cols['dist_bayesfactor'] = res.to_host('log_bf_corrected')
 	cols['dist_post'] = res.to_host('dist_post')
-	table = pandas.DataFrame(cols)
 
 	from . import magpriors
-	table, total = magpriors.apply_magnitude_biasing(match_tables, table, res, mag_include_radius, mag_exclude_radius,
-		magauto_post_single_minvalue, store_mag_hists, logger=logger)
+	total = magpriors.apply_magnitude_biasing(match_tables, cols, res, mag_include_radius, mag_exclude_radius,
+		magauto_post_single_minvalue, store_mag_hists, logger=logger)  # (adds the bias_* columns)
 	logger.log('')
 	logger.log('Computing final probabilities ...')
 	stats = magpriors.final_probabilities_device(res, total, prob_ratio_secondary)
-	table = table.assign(p_single=stats['p_single'], match_flag=stats['match_flag'].astype(numpy.int64),
-		prob_has_match=stats['p_any'], prob_this_match=stats['p_i'])
+	cols['p_single'] = stats['p_single']
+	cols['match_flag'] = stats['match_flag'].astype(numpy.int64)
+	cols['prob_has_match'] = stats['p_any']
+	cols['prob_this_match'] = stats['p_i']
+	table = pandas.DataFrame(cols, copy=False)  # (one frame over the host arrays, made once)
 	res.plan.release()
 	return _truncate_table(table, min_prob, logger=logger)
 

@@ -56,14 +56,15 @@ def write_histogram(filename, bins, hist_sel, hist_all):
 
 def apply_magnitude_biasing(match_tables, table, res, mag_include_radius, mag_exclude_radius,
 		magauto_post_single_minvalue, store_mag_hists, logger):
-	"""returns (table with bias_* columns, device tensor ``total`` = dist_bayesfactor + sum of log10 biases)"""
+	"""``table``: the columns of the match table so far (an ordered mapping name -> host array; the ``bias_*`` columns are added
+	to it -- the DataFrame is made once, at the end, by the caller); returns the device tensor ``total`` = dist_bayesfactor + sum
+	of log10 biases"""
 	from . import UndersampledException
 	t = _hip.torch()
 	lib = _hip.load()
 	device = res.plan.device
 	nrows = res.nrows
 	total = res.column('log_bf_corrected').clone()
-	bias_columns = {}
 	for i, tab in enumerate(match_tables):
 		for magvals, maghist, magname in zip(tab['mags'], tab['maghists'], tab['magnames']):
 			col = '%s_%s' % (tab['name'], magname)
@@ -73,12 +74,12 @@ def apply_magnitude_biasing(match_tables, table, res, mag_include_radius, mag_ex
 			mag_all[mag_all == -99] = numpy.nan  # in place, like the reference (:319)
 			if maghist is None:
 				if mag_include_radius is not None:
-					sep_max = table['Separation_max'].values
+					sep_max = table['Separation_max']
 					secure, plausible, weights = sep_max < mag_include_radius, sep_max < mag_exclude_radius, numpy.ones(nrows)
 				else:
-					post = table['dist_post'].values
+					post = table['dist_post']
 					secure, plausible, weights = post > magauto_post_single_minvalue, post > 0.01, post
-				target, target_weights, field, n_plausible = secure_and_field_sources(table[table.columns[i]].values, mag_all,
+				target, target_weights, field, n_plausible = secure_and_field_sources(table[tab['name']], mag_all,
 					secure, plausible, weights, 'api', mag)
 				logger.log('magnitude histogram of column "%s": %d secure matches, %d insecure matches and %d secure non-matches of %d total entries (%d valid)'
 					% (col, len(target), n_plausible, field.sum(), len(mag_all), numpy.isfinite(mag_all).sum()))
@@ -102,9 +103,8 @@ def apply_magnitude_biasing(match_tables, table, res, mag_include_radius, mag_ex
 			d_bias = t.empty(nrows, dtype=t.float64, device=device)
 			_hip.check(lib.nwayhip_bias_lookup(nrows, _hip.ptr(res.column('idx', i)), _hip.ptr(d_mag), len(func.edges),
 				_hip.ptr(d_edges), _hip.ptr(d_ratio), _hip.ptr(total), _hip.ptr(d_bias), _hip.current_stream_ptr(device)))
-			bias_columns['bias_%s' % col] = _hip.to_host(d_bias)
-	table = table.assign(**bias_columns)
-	return table, total
+			table['bias_%s' % col] = _hip.to_host(d_bias)
+	return total
 
 
 def final_probabilities_device(res, total, prob_ratio_secondary):
