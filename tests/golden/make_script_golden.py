@@ -436,6 +436,23 @@ def gen_ell():
 	save('script_ell', **arrays)
 	with open(os.path.join(HERE, 'script_ell.json'), 'w') as f:
 		json.dump(meta, f, indent=1, sort_keys=True)
+	# what fastskymatch.match_multiple RETURNED to the script (nway.py:267): the index array, the columns up to ``ncat`` (names, TFORMs, arrays as the
+	# Column holds them), the header -- with and without the per-axis offsets (circular=False / True)
+	mm_meta, mm = {}, {}
+	for tag, argv in (('mm_rot3', ELL_CASES[0][1]), ('mm_circ3', ['--radius', '15', 'X.fits', '1.0', 'O.fits', '0.8', 'I.fits', ':major', '--out', 'mm_circ3.fits'])):
+		g, log = run_script(argv)
+		names = [c.name for c in g['columns']]
+		upto = names.index('ncat') + 1
+		mm_meta[tag] = dict(argv=argv, radius_deg=float(g['match_radius']), circular=bool(g['simple_errors']) if tag == 'mm_circ3' else False, table_names=list(g['table_names']),
+			columns=names[:upto], formats=[c.format for c in g['columns'][:upto]], header=dict(g['match_header']))
+		for n in g['table_names']:
+			mm['%s/results/%s' % (tag, n)] = native(g['results'][n])
+		for c in g['columns'][:upto]:
+			mm['%s/col/%s' % (tag, c.name)] = native(c.array)
+		print('%-14s %7d rows, %d columns returned by match_multiple' % (tag, len(g['results']), upto))
+	save('script_mm', **mm)
+	with open(os.path.join(HERE, 'script_mm.json'), 'w') as f:
+		json.dump(mm_meta, f, indent=1, sort_keys=True)
 
 
 def error_inputs(write):

@@ -160,3 +160,40 @@ def test_nway_py_as_a_program(tmp_path):
 	compare_float(out.data['p_i'], g['ell2/p_i'], 'p_i')
 	head = _fits.read_header(str(tmp_path / 'ell2.fits'), 0)
 	assert head['NWAYCMD'] == ' '.join([script] + list(meta['argv']))
+
+
+@pytest.mark.parametrize('tag', ['mm_rot3', 'mm_circ3'])
+def test_match_multiple_returns_what_it_returned_to_the_script(tag, tmp_path):
+	"""``fastskymatch.match_multiple`` (fastskymatch.py:228-342) against what the reference's returned to the script at nway.py:267
+	(tests/golden/script_mm.*: recorded from the script's globals): the index array field by field, the columns up to ``ncat`` in the
+	same order with the same TFORMs, their values (input copies and indices exactly; the 'E' separations as float32, one ulp for the
+	device's libm; the per-axis offsets of circular=False as in the table test above), the two header keys"""
+	from nway_amd import _fits, NullOutputLogger
+	from nway_amd.fastskymatch import match_multiple
+	meta = json.load(open(os.path.join(GOLDEN, 'script_mm.json')))[tag]
+	g = golden('script_mm')
+	stage_inputs('rot3', tmp_path)
+	tables = [_fits.read_table(str(tmp_path / (n + '.fits'))) for n in meta['table_names']]
+	results, columns, header = match_multiple([t.data for t in tables], meta['table_names'], meta['radius_deg'], [t.formats for t in tables],
+		logger=NullOutputLogger(), circular=meta['circular'])
+	for n in meta['table_names']:
+		np.testing.assert_array_equal(results[n], g['%s/results/%s' % (tag, n)], err_msg=n)
+	assert [c.name for c in columns] == meta['columns']
+	assert [c.format for c in columns] == meta['formats']
+	for c in columns:
+		want = g['%s/col/%s' % (tag, c.name)]
+		if want.dtype.kind in 'iu':
+			np.testing.assert_array_equal(np.asarray(c.array, dtype=np.int64), want.astype(np.int64), err_msg=c.name)
+		elif c.format == 'D':
+			np.testing.assert_array_equal(np.asarray(c.array, dtype=float), want, err_msg=c.name)
+		else:
+			assert want.dtype == np.float32
+			with np.errstate(invalid='ignore'):
+				got = np.asarray(c.array, dtype=float).astype(np.float32)
+			if c.name.endswith('_ra') or c.name.endswith('_dec'):
+				compare_float(got, want, c.name, OFFSET_RTOL, OFFSET_ATOL)
+			else:
+				compare_float(got, want, c.name, 2.4e-7, 0.0)
+	for key in ('COLS_RA', 'COLS_DEC'):
+		assert header[key] == meta['header'][key]
+	assert sorted(header) == ['COLS_DEC', 'COLS_RA']
