@@ -574,6 +574,8 @@ def main():
 		help='who carries the exchanges of the multi-GPU modes: torch.distributed (default) or the library\'s own RCCL calls behind the C ABI (nwayhip_comm_*)')
 	ap.add_argument('--extras', type=int, default=int(os.environ.get('NWAY_BENCH_EXTRAS', '1')),
 		help='N > 1: also measure, in the same launch, the fixed-size jobs BASELINE names for several GPUs (extra_configs: C3-S as one job, configs[3], configs[4]; both sharding modes, both carriers of the exchanges); 0 = skip')
+	ap.add_argument('--extras-watchdog', type=float, default=float(os.environ.get('NWAY_BENCH_EXTRAS_WATCHDOG', '600')),
+		help='N > 1: seconds after which a hung block of extra configurations is abandoned and the (already measured) headline printed')
 	ap.add_argument('--fixed-jobs', type=int, default=int(os.environ.get('NWAY_BENCH_FIXED_JOBS', '1')),
 		help='also measure, as ONE job on ONE GPU, the fixed-size jobs BASELINE names (configs[3], configs[4]; with N > 1 also configs[2]): '
 		'the N = 1 point of their strong-scaling curves, in this launch (rank 0, the other ranks wait); 0 = skip')
@@ -885,33 +887,65 @@ def main():
 		dist.all_reduce(seen)
 		ranks_seen = int(seen.item())
 	extras = None
-	if (world > 1 or force_dist) and args.extras:
-		# (every rank takes part; the headline's engine has been measured and is released first)
-		if engine is not None:
-			if getattr(engine, 'plan', None) is not None:
+	n1 = None
+	watchdog = None
+	multi = world > 1 or force_dist
+	if multi and (args.extras or args.fixed_jobs):
+		# The blocks below (fixed-size jobs in several multi-GPU modes, the one-GPU references) run collectives that no machine
+		# with more than one GPU has executed yet.  The headline above is measured: whatever happens to them -- a hang, an error on
+		# one rank -- it must still come out.  After --extras-watchdog seconds the other ranks leave and rank 0 prints the line as it
+		# stands; an exception in the blocks does the same at once.
+		import threading
+		import traceback
+		once = threading.Lock()
+
+		def give_up(reason):
+			if not once.acquire(False):
+				time.sleep(60)  # (the other thread is printing; it ends the process)
+				return
+			if rank == 0:
+				out['ranks_seen'] = ranks_seen
+				out['extra_configs'] = [dict(error=reason)]
+				sys.stdout.write(json.dumps(out) + '\n')
+				sys.stdout.flush()
+			os._exit(0)
+		watchdog = threading.Timer(args.extras_watchdog + (2.0 if rank == 0 else 0.0), give_up,
+			['the extra configurations did not finish within %g s: the watchdog printed the headline and ended the run' % args.extras_watchdog])
+		watchdog.daemon = True
+		watchdog.start()
+	try:
+		if multi and args.extras:
+			# (every rank takes part; the headline's engine has been measured and is released first)
+			if engine is not None:
+				if getattr(engine, 'plan', None) is not None:
+					engine.plan.close()
+				engine = None
+				plan = None
+				plans = []
+				torch.cuda.empty_cache()
+			extras = extra_configs(args, world, rank, device, dist, backend)
+		if args.fixed_jobs and ((multi and args.extras) or (not multi and args.cpu_sample != 0)):
+			# (with N > 1 they belong to the extra_configs block; a profiling / A-B invocation -- --cpu-sample 0 on one GPU -- measures the headline only)
+			if engine is not None and getattr(engine, 'plan', None) is not None:
 				engine.plan.close()
 			engine = None
-			plan = None
-			plans = []
+			if not multi:
+				for pl in plans:
+					pl.close()
+				plans, plan = [], None
+				cats = sec_copies = None
 			torch.cuda.empty_cache()
-		extras = extra_configs(args, world, rank, device, dist, backend)
-	n1 = None
-	multi = world > 1 or force_dist
-	if args.fixed_jobs and ((multi and args.extras) or (not multi and args.cpu_sample != 0)):
-		# (with N > 1 they belong to the extra_configs block; a profiling / A-B invocation -- --cpu-sample 0 on one GPU -- measures the headline only)
-		if engine is not None and getattr(engine, 'plan', None) is not None:
-			engine.plan.close()
-		engine = None
-		if world == 1 and not force_dist:
-			for pl in plans:
-				pl.close()
-			plans, plan = [], None
-			cats = sec_copies = None
-		torch.cuda.empty_cache()
-		if rank == 0:
-			n1 = single_gpu_jobs(args, device, ['c4s', 'c5'] + (['c3s'] if (world > 1 or force_dist) else []))
-		if world > 1 or force_dist:
-			dist.barrier()  # (the other ranks wait here while rank 0 measures the one-GPU references)
+			if rank == 0:
+				n1 = single_gpu_jobs(args, device, ['c4s', 'c5'] + (['c3s'] if multi else []))
+			if multi:
+				dist.barrier()  # (the other ranks wait here while rank 0 measures the one-GPU references)
+	except Exception as e:
+		if watchdog is None:
+			raise
+		traceback.print_exc()
+		give_up('the extra configurations ended with %s: %s (rank %d); the headline above was measured before them' % (type(e).__name__, e, rank))
+	if watchdog is not None:
+		watchdog.cancel()
 	if rank == 0:
 		out['ranks_seen'] = ranks_seen
 		if extras is not None:

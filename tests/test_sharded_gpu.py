@@ -372,6 +372,25 @@ def test_bench_eight_gloo_ranks_share_the_gpu(tmp_path):
 			f.write(line + '\n')
 
 
+def test_bench_headline_survives_hung_extras(tmp_path):
+	"""the blocks after the headline (fixed-size jobs in the multi-GPU modes) run collectives no multi-GPU machine has executed yet:
+	when they do not finish within --extras-watchdog seconds, rank 0 prints the measured headline with an error record and every rank
+	leaves with status 0 (here: two gloo ranks on the one GPU and a watchdog that fires at once)"""
+	env = dict(os.environ, NWAY_BENCH_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0', NWAY_BENCH_EXTRA_SCALE='0.02')
+	cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+		'--master-port', str(free_port()), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '4', '--warmup', '2', '--prewarm', '3',
+		'--n-primary', '5000', '--n-secondary', '800000', '--extras-watchdog', '0.05']
+	res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, timeout=600, env=env, cwd=ROOT)
+	assert res.returncode == 0, res.stderr[-3000:]
+	lines = [l for l in res.stdout.splitlines() if l.startswith('{')]
+	assert len(lines) == 1
+	out = json.loads(lines[0])
+	assert out['n_gpus'] == 2 and out['ranks_seen'] == 2 and out['value'] > 0 and out['ms_per_step'] > 0
+	# (either rank 0's own timer, or the broken collective it was in when the other rank left)
+	err = out['extra_configs'][0]['error']
+	assert 'watchdog' in err or 'measured before them' in err, err
+
+
 def mag_worker(rank, world, port, outfile, mode):
 	os.environ['MASTER_ADDR'] = '127.0.0.1'
 	os.environ['MASTER_PORT'] = str(port)
