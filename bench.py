@@ -348,7 +348,7 @@ def extra_configs(args, world, rank, device, dist, backend):
 	comms = ['torch'] + (['rccl'] if backend == 'nccl' else [])
 	steps, warm = min(args.steps, 20), min(max(args.warmup, 2), 5)
 	records = []
-	budget_s = float(os.environ.get('NWAY_BENCH_EXTRA_BUDGET', '300'))  # the whole block is skipped job by job once this is spent
+	budget_s = float(os.environ.get('NWAY_BENCH_EXTRA_BUDGET', '200'))  # the whole block is skipped job by job once this is spent
 	t_start = time.perf_counter()
 
 	def agreed(ok):
@@ -574,7 +574,7 @@ def main():
 		help='who carries the exchanges of the multi-GPU modes: torch.distributed (default) or the library\'s own RCCL calls behind the C ABI (nwayhip_comm_*)')
 	ap.add_argument('--extras', type=int, default=int(os.environ.get('NWAY_BENCH_EXTRAS', '1')),
 		help='N > 1: also measure, in the same launch, the fixed-size jobs BASELINE names for several GPUs (extra_configs: C3-S as one job, configs[3], configs[4]; both sharding modes, both carriers of the exchanges); 0 = skip')
-	ap.add_argument('--extras-watchdog', type=float, default=float(os.environ.get('NWAY_BENCH_EXTRAS_WATCHDOG', '600')),
+	ap.add_argument('--extras-watchdog', type=float, default=float(os.environ.get('NWAY_BENCH_EXTRAS_WATCHDOG', '480')),
 		help='N > 1: seconds after which a hung block of extra configurations is abandoned and the (already measured) headline printed')
 	ap.add_argument('--fixed-jobs', type=int, default=int(os.environ.get('NWAY_BENCH_FIXED_JOBS', '1')),
 		help='also measure, as ONE job on ONE GPU, the fixed-size jobs BASELINE names (configs[3], configs[4]; with N > 1 also configs[2]): '
