@@ -494,13 +494,14 @@ def single_gpu_jobs(args, device, names, budget_s=240.0):
 				pass_frac=jb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, path=plan.description)
 			if name == 'c5' and os.environ.get('NWAY_BENCH_LOCAL_ZONES', '1') != '0':
 				# the same job with the catalogues bucketed into declination zones at set-up (ZoneShardedMatch on ONE rank, round 5): every
-				# zone's cell table fits the LDS of a sweep workgroup, where the job as one zone needs the large-table sweep
+				# zone's cell table fits the LDS of a sweep workgroup, where the job as one zone needs the large-table sweep; round 6: the
+				# zones of a step go out as ONE launch set (one registration, one sweep, one tail launch: nwayhip_zones_enqueue)
 				plan.close()
 				plan = None
 				cats = None
 				torch.cuda.empty_cache()
 				from nway_amd import distributed
-				eng = distributed.ZoneShardedMatch(tabs[0], tabs[1:], radius, args.completeness, device, zones_per_rank=8, streams=2, local_only=True)
+				eng = distributed.ZoneShardedMatch(tabs[0], tabs[1:], radius, args.completeness, device, zones_per_rank=8, local_only=True)
 				try:
 					t0 = time.perf_counter()
 					while time.perf_counter() - t0 < 0.03:  # (24 short launches per pass: the clocks of an idle GPU take ~10 ms to come up)
@@ -512,9 +513,9 @@ def single_gpu_jobs(args, device, names, budget_s=240.0):
 					torch.cuda.synchronize(device)
 					msz = (time.perf_counter() - t0) * 1e3 / steps
 					stz = eng.read_status()
-					rec['zones'] = dict(zones=8, streams=2, ms_per_step=msz, rows=int(stz[_hip.ST_ROWS]), value=int(stz[_hip.ST_ROWS]) / (msz * 1e-3), flags=int(stz[_hip.ST_FLAGS]),
+					rec['zones'] = dict(zones=8, one_launch_set=bool(eng.batched), ms_per_step=msz, rows=int(stz[_hip.ST_ROWS]), value=int(stz[_hip.ST_ROWS]) / (msz * 1e-3), flags=int(stz[_hip.ST_FLAGS]),
 						pass_frac=jb / (msz * 1e-3) / 1e9 / HBM_PEAK_GBS, setup_s=eng.setup_seconds,
-						note='ZoneShardedMatch(zones_per_rank=8, streams=2) on one rank: the one-time bucketing of the catalogues by zone is set-up, like the exchanges of the multi-GPU modes')
+						note='ZoneShardedMatch(zones_per_rank=8) on one rank, the zones of a step as one launch set: the one-time bucketing of the catalogues by zone is set-up, like the exchanges of the multi-GPU modes')
 				finally:
 					eng.close()
 		except Exception as e:

@@ -25,7 +25,8 @@
 extern "C" {
 #endif
 
-#define NWAYHIP_ABI_VERSION 2            /* nwayhip_version(); 2 (round 4): nwayhip_log_bf_elliptical gained f32_offsets in round 3 without a
+#define NWAYHIP_ABI_VERSION 3            /* nwayhip_version(); 3 (round 6): nwayhip_zones_*, nwayhip_plan_profile_samples (round 5, unbumped then);
+                                            2 (round 4): nwayhip_log_bf_elliptical gained f32_offsets in round 3 without a
                                             bump, NWAYHIP_ENABLE_FUSED_FRONT / NWAYHIP_FLAG_BARRIER / NWAYHIP_DESC_FUSED_FRONT are gone */
 #define NWAYHIP_MAXCAT 8                 /* catalogues per match (primary + 7) */
 #define NWAYHIP_MAXPAIR 28               /* MAXCAT*(MAXCAT-1)/2 separation columns */
@@ -242,6 +243,35 @@ int32_t nwayhip_plan_split_capable(const nwayhip_plan* plan);
  * pointer is always safe; after scribbling over a workspace, destroy the plan and make a new one. */
 int nwayhip_match_enqueue(nwayhip_plan* plan, const nwayhip_catalogue* h_cats, void* workspace,
 	size_t workspace_bytes, const nwayhip_table* h_table, int64_t* d_status, void* stream);
+
+/* ---- several zones of one job as ONE launch set -------------------------------------------------
+ * (The reference fills ONE bucket table per job, fastskymatch.py:118-160; a job whose table outgrows the LDS of a sweep
+ * workgroup is cut into declination zones, each an ordinary plan of its own -- nway_amd/distributed.py: ZoneShardedMatch.)
+ * Run one by one, Z zones pay the fixed latencies of a pass Z times.  A zones object holds the plans of the zones and
+ * enqueues ALL their registrations as one launch, all their sweeps as one launch, all their tails as one launch: the
+ * workgroups of a launch are shared out among the zones (the sweep's in proportion to the sources a zone streams), every
+ * zone's argument block lives in `d_args` (device memory of the caller, nwayhip_zones_args_bytes(), 256-byte aligned;
+ * written by the library with a stream-ordered copy whenever a block changes -- catalogue or table pointers, not every run).
+ * Every zone keeps its own workspace, table and status block: results and status words are exactly those of the zones'
+ * own nwayhip_match_enqueue calls.  Batched where every plan takes the sparse front with the bitmap in LDS and the 2-way
+ * sparse tail (NWAYHIP_SWEEP_LDS + NWAYHIP_TAIL_SPARSE2) and has run once on its workspace (its first run clears it);
+ * otherwise -- and always correctly -- the zones are enqueued one after the other.  nwayhip_zones_batched(): which of the
+ * two the last enqueue was.  The plans must outlive the object; nwayhip_plan_profile on the FIRST plan brackets the
+ * launches of the whole set. */
+typedef struct nwayhip_zones nwayhip_zones;
+typedef struct nwayhip_zone_run {
+	const nwayhip_catalogue* h_cats;     /* as nwayhip_match_enqueue, per zone */
+	void* workspace;
+	size_t workspace_bytes;
+	const nwayhip_table* h_table;
+	int64_t* d_status;
+} nwayhip_zone_run;
+#define NWAYHIP_MAXZONES 64
+int nwayhip_zones_create(nwayhip_zones** zones, nwayhip_plan* const* h_plans, int32_t nplans);
+int nwayhip_zones_destroy(nwayhip_zones* zones);
+size_t nwayhip_zones_args_bytes(const nwayhip_zones* zones);
+int nwayhip_zones_enqueue(nwayhip_zones* zones, const nwayhip_zone_run* h_runs /*[nplans]*/, void* d_args, size_t d_args_bytes, void* stream);
+int32_t nwayhip_zones_batched(const nwayhip_zones* zones);
 
 /* ---- secondary-split mode: several GPUs on ONE job ---------------------------------------
  * (second half; the reference is a single process.)  Every rank registers ALL

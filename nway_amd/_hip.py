@@ -30,7 +30,8 @@ STAGE_NAMES = ['register', 'sweep', 'pairs', 'lists', 'expand', 'rows', 'groups'
 CORRECTION_NONE, CORRECTION_CLI = 0, 1
 DISABLE_DENSE3, DISABLE_HYBRID, DISABLE_FUSED_CORRECTION, DISABLE_ONE_SWEEP, DISABLE_QUAD3 = 1, 2, 4, 8, 16
 ENABLE_QUAD3 = 2
-ABI_VERSION = 2  # include/nwayhip.h: NWAYHIP_ABI_VERSION
+ABI_VERSION = 3  # include/nwayhip.h: NWAYHIP_ABI_VERSION
+MAXZONES = 64
 DESC_WORDS = 8
 DESC_NAMES = ['path', 'link_slots', 'direct_log2', 'sweep', 'tail', 'fold_log2', 'one_sweep', 'reserved']
 SWEEP_GENERAL, SWEEP_LDS, SWEEP_BIG = 0, 1, 2
@@ -74,6 +75,12 @@ class Split(ctypes.Structure):
 		('capacity', ctypes.c_int64), ('d_export', ctypes.c_void_p), ('d_import', ctypes.c_void_p)]
 
 
+class ZoneRun(ctypes.Structure):
+	"""nwayhip_zone_run: what nwayhip_match_enqueue takes, per zone of a launch set"""
+	_fields_ = [('h_cats', ctypes.POINTER(Catalogue)), ('workspace', ctypes.c_void_p), ('workspace_bytes', ctypes.c_size_t),
+		('h_table', ctypes.POINTER(Table)), ('d_status', ctypes.c_void_p)]
+
+
 # every symbol include/nwayhip.h declares: (restype, argtypes)
 _vp, _i64, _i32, _dbl = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_double
 SYMBOLS = {
@@ -97,6 +104,11 @@ SYMBOLS = {
 	'nwayhip_plan_describe': (ctypes.c_int, [_vp, ctypes.POINTER(_i32)]),
 	'nwayhip_plan_split_capable': (ctypes.c_int32, [_vp]),
 	'nwayhip_match_enqueue': (ctypes.c_int, [_vp, ctypes.POINTER(Catalogue), _vp, ctypes.c_size_t, ctypes.POINTER(Table), _vp, _vp]),
+	'nwayhip_zones_create': (ctypes.c_int, [ctypes.POINTER(_vp), ctypes.POINTER(_vp), _i32]),
+	'nwayhip_zones_destroy': (ctypes.c_int, [_vp]),
+	'nwayhip_zones_args_bytes': (ctypes.c_size_t, [_vp]),
+	'nwayhip_zones_enqueue': (ctypes.c_int, [_vp, ctypes.POINTER(ZoneRun), _vp, ctypes.c_size_t, _vp]),
+	'nwayhip_zones_batched': (ctypes.c_int32, [_vp]),
 	'nwayhip_split_buffer_bytes': (ctypes.c_size_t, [_vp, _i32, _i64]),
 	'nwayhip_split_front_enqueue': (ctypes.c_int, [_vp, ctypes.POINTER(Catalogue), _vp, ctypes.c_size_t, ctypes.POINTER(Split), _vp, _vp]),
 	'nwayhip_split_back_enqueue': (ctypes.c_int, [_vp, ctypes.POINTER(Catalogue), _vp, ctypes.c_size_t, ctypes.POINTER(Split), ctypes.POINTER(Table), _vp, _vp]),
@@ -139,12 +151,15 @@ def load():
 		raise NwayHipError('HIP library %s is not built; run "python -m nway_amd.build" (needs hipcc). '
 			'There is no CPU fallback.' % path)
 	lib = ctypes.CDLL(path)
+	# (the version first: an older library lacks symbols the binding below would ask for)
+	lib.nwayhip_version.restype = ctypes.c_int
+	lib.nwayhip_version.argtypes = []
+	if lib.nwayhip_version() != ABI_VERSION:
+		raise NwayHipError('ABI version mismatch: library %s has %d, binding %d (rebuild: python -m nway_amd.build --force)' % (path, lib.nwayhip_version(), ABI_VERSION))
 	for name, (restype, argtypes) in SYMBOLS.items():
 		fn = getattr(lib, name)
 		fn.restype = restype
 		fn.argtypes = argtypes
-	if lib.nwayhip_version() != ABI_VERSION:
-		raise NwayHipError('ABI version mismatch: library %d, binding %d' % (lib.nwayhip_version(), ABI_VERSION))
 	_lib = lib
 	return lib
 
@@ -687,10 +702,63 @@ class MatchPlan(object):
 			pass
 
 
+class ZoneBatch(object):
+	"""Several settled plans -- the declination zones of one job -- enqueued as ONE launch set (include/nwayhip.h:
+	nwayhip_zones_*): one registration, one sweep and one tail launch for all of them instead of three per zone.  Every plan
+	keeps its workspace, table and status block; ``enqueue`` takes the zones' catalogue lists in the plans' order.  Where
+	the plans do not qualify (see the header) the zones go out one after the other: ``batched`` says which it was."""
+
+	def __init__(self, plans):
+		self.lib = load()
+		self.plans = list(plans)
+		if not 1 <= len(self.plans) <= MAXZONES:
+			raise ValueError('a launch set takes 1..%d zones' % MAXZONES)
+		self.device = self.plans[0].device
+		handles = (ctypes.c_void_p * len(self.plans))(*[p.handle for p in self.plans])
+		h = ctypes.c_void_p()
+		check(self.lib.nwayhip_zones_create(ctypes.byref(h), handles, len(self.plans)))
+		self.handle = h
+		t = torch()
+		self.args_bytes = int(self.lib.nwayhip_zones_args_bytes(self.handle))
+		self.args = t.empty(self.args_bytes + 256, dtype=t.uint8, device=self.device)
+		self.args_ptr = (self.args.data_ptr() + 255) // 256 * 256
+		self._runs = (ZoneRun * len(self.plans))()
+		self._cats = [None] * len(self.plans)
+
+	def enqueue(self, catalogues, stream=None):
+		"""catalogues: per zone the list of its DeviceCatalogues; does not synchronise"""
+		for z, (plan, cats) in enumerate(zip(self.plans, catalogues)):
+			self._cats[z] = (Catalogue * plan.ncat)(*[c.struct() for c in cats])  # (kept alive until the call returns)
+			r = self._runs[z]
+			r.h_cats = self._cats[z]
+			r.workspace = plan.ws_ptr
+			r.workspace_bytes = plan.ws_len
+			r.h_table = ctypes.pointer(plan.table_struct)
+			r.d_status = plan.status.data_ptr()
+		s = stream if stream is not None else current_stream_ptr(self.device)
+		check(self.lib.nwayhip_zones_enqueue(self.handle, self._runs, ctypes.c_void_p(self.args_ptr), self.args_bytes, s))
+
+	@property
+	def batched(self):
+		"""whether the last enqueue went out as one launch set"""
+		return bool(self.lib.nwayhip_zones_batched(self.handle))
+
+	def close(self):
+		if getattr(self, 'handle', None):
+			self.lib.nwayhip_zones_destroy(self.handle)
+			self.handle = None
+
+	def __del__(self):
+		try:
+			self.close()
+		except Exception:
+			pass
+
+
 def make_params(ncat, scheme, radius_arcsec, err_deg, dens, dens_plus, prior_table, prob_ratio_secondary=0.5,
 		radius_filter=True, correction=CORRECTION_NONE, finalize=True, sphere_cell_factor=0.0, bitmap_bits=0, link_slots=0, table_slots=0, f32_roundtrip=False,
 		tuning=None):
-	"""tuning: dict with any of direct_log2, fold_log2, disable (DISABLE_* mask), enable (ENABLE_* mask), link_slots -- what tests and
+	"""tuning: dict with any of direct_log2, fold_log2, disable (DISABLE_* mask), enable (ENABLE_* mask), link_slots, sphere_cell_factor -- what tests and
 	benchmarks use to force a path (nwayhip.h: nwayhip_match_params); None = the library decides"""
 	p = MatchParams()
 	tuning = dict(tuning or {})
@@ -699,6 +767,7 @@ def make_params(ncat, scheme, radius_arcsec, err_deg, dens, dens_plus, prior_tab
 	p.fold_log2 = int(tuning.pop('fold_log2', 0))
 	p.disable = int(tuning.pop('disable', 0))
 	p.enable = int(tuning.pop('enable', 0))
+	sphere_cell_factor = float(tuning.pop('sphere_cell_factor', sphere_cell_factor))
 	if tuning:
 		raise ValueError('unknown tuning keys: %s' % sorted(tuning))
 	p.table_slots = table_slots

@@ -91,6 +91,7 @@ static void dev_launch_note(const char* name, int state, int line) {
 #include "rows.inc"
 #include "finish2.inc"
 #include "tail2.inc"
+#include "zones.inc"
 #include "taild.inc"
 #include "tailk.inc"
 #include "tail3q.inc"

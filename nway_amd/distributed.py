@@ -850,7 +850,7 @@ class ZoneShardedMatch(MagnitudePriors):
 	ZONE_BINS = 1 << 16
 
 	def __init__(self, primary, secondaries, match_radius, prior_completeness, device, group=None,
-			prob_ratio_secondary=0.5, tuning=None, comm=None, zones_per_rank=1, streams=1, local_only=False):
+			prob_ratio_secondary=0.5, tuning=None, comm=None, zones_per_rank=1, streams=1, local_only=False, one_launch=True):
 		"""local_only: this process alone, whatever process group is up (the catalogues handed in are the WHOLE catalogues; no collective
 		is issued) -- ``bench.py`` measures the one-GPU reference of a job on rank 0 that way while the other ranks wait.
 		zones_per_rank: every rank holds this many declination zones and runs them one after the other in a step (round 5).
@@ -858,7 +858,11 @@ class ZoneShardedMatch(MagnitudePriors):
 		workgroup where the one big zone would need the large-table sweep (5e5 x 1e8 on ONE GPU: 729 us as one zone) -- and with
 		``streams`` > 1 the zones of a step are enqueued round robin on that many HIP streams, so that the latency-bound ends of
 		one zone's pass (registration, routing chain, tail) run beside the stream of another's.  The table does not depend on
-		either number."""
+		either number.
+		one_launch (round 6; with ``streams`` == 1): the zones of a step go out as ONE launch set -- one registration, one sweep,
+		one tail launch for all of them (``_hip.ZoneBatch``, include/nwayhip.h: nwayhip_zones_*) -- instead of three launches per
+		zone: the fixed latencies of a pass are paid once per step, not once per zone.  Where the zones' plans do not qualify
+		(2-way sparse tail, table in LDS) the library enqueues them one after the other; ``batched`` tells."""
 		if isinstance(secondaries, dict):
 			secondaries = [secondaries]
 		if comm not in (None, 'torch'):
@@ -877,6 +881,9 @@ class ZoneShardedMatch(MagnitudePriors):
 		self.rank, self.world = (0, 1) if local_only else world_info(group)
 		self.zones_per_rank = max(1, int(zones_per_rank))
 		self.nstreams = max(1, int(streams))
+		self.one_launch = bool(one_launch)
+		self._batch = None
+		self.batched = False
 		self.plan = None
 		self.setup_seconds = None
 		self.setup()
@@ -1039,6 +1046,9 @@ class ZoneShardedMatch(MagnitudePriors):
 		for z in self.zones:
 			self._build_zone(z)
 		self._streams = None
+		if self._batch is not None:
+			self._batch.close()
+			self._batch = None
 		z0 = self.zones[0]
 		self.plan, self.cats, self.empty, self.status = z0['plan'], z0['cats'], all(z['empty'] for z in self.zones), z0['status']
 
@@ -1063,9 +1073,18 @@ class ZoneShardedMatch(MagnitudePriors):
 		round robin on that many streams, which start behind the work already on the current stream and which the current stream
 		waits for at the end (whatever follows on it sees the finished tables)"""
 		live = [z for z in self.zones if not z['empty']]
+		if cats is not None and len(self.zones) > 1:
+			raise ValueError('ZoneShardedMatch.step(cats=...) stands for the catalogues of ONE zone: this rank holds %d' % len(self.zones))
+		if len(live) > 1 and self.nstreams == 1 and self.one_launch:
+			from nway_amd import _hip
+			if self._batch is None:
+				self._batch = _hip.ZoneBatch([z['plan'] for z in live])
+			self._batch.enqueue([z['cats'] for z in live])
+			self.batched = self._batch.batched
+			return
 		if len(live) <= 1 or self.nstreams == 1:
 			for z in live:
-				self._step_zone(z, cats if (cats is not None and len(self.zones) == 1) else None, None)
+				self._step_zone(z, cats, None)
 			return
 		import torch
 		if self._streams is None:
@@ -1114,6 +1133,9 @@ class ZoneShardedMatch(MagnitudePriors):
 		return int(t.item())
 
 	def close(self):
+		if getattr(self, '_batch', None) is not None:
+			self._batch.close()
+			self._batch = None
 		for z in self.zones:
 			if z.get('plan') is not None:
 				z['plan'].close()

@@ -35,7 +35,7 @@ def test_library_exports_every_declared_symbol(built):
 		assert hasattr(lib, name), 'libnwayhip.so does not export %s' % name
 	assert sorted(_hip.SYMBOLS) == declared, 'ctypes binding and header disagree'
 	bound = _hip.load()
-	assert bound.nwayhip_version() == _hip.ABI_VERSION == 2
+	assert bound.nwayhip_version() == _hip.ABI_VERSION == 3
 	assert isinstance(bound.nwayhip_last_error(), bytes)
 
 
@@ -62,6 +62,33 @@ def test_plan_rejects_bad_arguments(built):
 	assert lib.nwayhip_plan_destroy(handle) == 0
 	n = (ctypes.c_int64 * 2)(0, 10)
 	assert lib.nwayhip_plan_create(ctypes.byref(handle), ctypes.byref(p), n, 100, 100) != 0
+
+
+def test_zone_launch_set_rejects_bad_arguments(built):
+	"""nwayhip_zones_create (round 6): plan count, null plans, zones of different jobs; no device is touched before an enqueue"""
+	from nway_amd import _hip
+	lib = _hip.load()
+	assert ctypes.sizeof(_hip.ZoneRun) == 5 * 8
+	n = (ctypes.c_int64 * 2)(10, 10)
+	handles = []
+	for scheme in (_hip.SCHEME_FLAT, _hip.SCHEME_FLAT, _hip.SCHEME_SPHERE):
+		h = ctypes.c_void_p(0)
+		p = _hip.make_params(2, scheme, 5.0, 5.0 / 3600, [1., 1.], [1., 1.], [1., 1.])
+		assert lib.nwayhip_plan_create(ctypes.byref(h), ctypes.byref(p), n, 100, 100) == 0
+		handles.append(h)
+	zs = ctypes.c_void_p(0)
+	arr = (ctypes.c_void_p * 2)(handles[0], handles[1])
+	assert lib.nwayhip_zones_create(ctypes.byref(zs), arr, 0) != 0 and b'plans' in lib.nwayhip_last_error()
+	assert lib.nwayhip_zones_create(ctypes.byref(zs), arr, _hip.MAXZONES + 1) != 0
+	assert lib.nwayhip_zones_create(ctypes.byref(zs), (ctypes.c_void_p * 2)(handles[0], None), 2) != 0 and b'null' in lib.nwayhip_last_error()
+	assert lib.nwayhip_zones_create(ctypes.byref(zs), (ctypes.c_void_p * 2)(handles[0], handles[2]), 2) != 0 and b'scheme' in lib.nwayhip_last_error()
+	assert lib.nwayhip_zones_create(ctypes.byref(zs), arr, 2) == 0
+	assert lib.nwayhip_zones_args_bytes(zs) > 0 and lib.nwayhip_zones_args_bytes(zs) % 512 == 0
+	assert lib.nwayhip_zones_batched(zs) == 0
+	assert lib.nwayhip_zones_enqueue(zs, None, None, 0, None) != 0
+	assert lib.nwayhip_zones_destroy(zs) == 0
+	for h in handles:
+		assert lib.nwayhip_plan_destroy(h) == 0
 
 
 def test_no_cpu_fallback_without_gpu(built):

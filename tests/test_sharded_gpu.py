@@ -503,3 +503,83 @@ def test_zones_holding_one_source_or_none():
 		assert len(got['ncat']) == len(want) > 40
 		for key in want.columns:
 			np.testing.assert_array_equal(got[key], want[key].values, err_msg=key)
+
+
+@pytest.mark.parametrize('flat,zpr', [(False, 4), (True, 3), (False, 8)])
+def test_zones_of_a_rank_as_one_launch_set(flat, zpr):
+	"""round 6 (include/nwayhip.h: nwayhip_zones_*): the zones of a rank go out as ONE registration, ONE sweep and ONE tail launch --
+	every zone's table, status words and counters are those of the zones enqueued one after the other, and the gathered table
+	is the single-GPU table of the whole job bit for bit; step after step (the two frames of argument blocks alternate with the
+	two scratch copies of the plans)"""
+	import nway_amd as nw
+	from nway_amd import distributed, _hip
+	tabs = catalogues(2, flat)
+	dev = torch.device('cuda', 0)
+	want = nw.nway_match(tabs, 10., 0.9, logger=nw.NullOutputLogger())
+	serial = distributed.ZoneShardedMatch(tabs[0], tabs[1:], 10., 0.9, dev, zones_per_rank=zpr, local_only=True, one_launch=False)
+	serial.step()
+	assert not serial.batched
+	st_serial = [np.asarray(serial._zone_status(z)).copy() for z in serial.zones]
+	eng = distributed.ZoneShardedMatch(tabs[0], tabs[1:], 10., 0.9, dev, zones_per_rank=zpr, local_only=True)
+	for step in range(5):
+		eng.step()
+		assert eng.batched, 'the zones of a 2-way sparse job qualify for one launch set'
+		for z, st in zip(eng.zones, st_serial):
+			got = np.asarray(eng._zone_status(z))
+			assert int(got[_hip.ST_FLAGS]) == 0
+			# (rows, registrations and links; the survivor counters depend on which of two colliding registrations was displaced)
+			for w in (_hip.ST_ROWS, _hip.ST_REGISTRATIONS, _hip.ST_PAIRS):
+				assert int(got[w]) == int(st[w]), 'status word %d of a zone, step %d' % (w, step)
+		if step in (0, 1, 4):
+			got = eng.gather_table()
+			assert len(got['ncat']) == len(want) > len(tabs[0]['ra'])
+			for key in want.columns:
+				np.testing.assert_array_equal(got[key], want[key].values, err_msg='%s, step %d' % (key, step))
+	serial.close()
+	eng.close()
+
+
+def test_zone_launch_set_through_the_c_abi():
+	"""nwayhip_zones_enqueue on plans of the caller's own: a set of ONE plan, a plan on a workspace it has not seen (its first run
+	clears it) and a 3-way plan are enqueued one after the other (nwayhip_zones_batched() == 0) with the same result; a null
+	argument buffer likewise; two sparse 2-way plans that have run once go out as one launch set"""
+	import nway_amd as nw
+	from nway_amd import _hip
+	dev = torch.device('cuda', 0)
+	tabs = catalogues(2, False)
+	half = len(tabs[0]['ra']) // 2
+	parts = [dict(tabs[0], ra=tabs[0]['ra'][:half], dec=tabs[0]['dec'][:half], error=tabs[0]['error'][:half]),
+		dict(tabs[0], ra=tabs[0]['ra'][half:], dec=tabs[0]['dec'][half:], error=tabs[0]['error'][half:])]
+	dens, dens_plus = nw._densities_from_sizes(['A', 'B'], [len(tabs[0]['ra']), len(tabs[1]['ra'])], [tabs[0]['area'], tabs[1]['area']], nw.NullOutputLogger())
+	params = _hip.make_params(2, _hip.SCHEME_SPHERE, 10., 10. / 3600, dens, dens_plus, nw._prior_table(dens, dens_plus, nw._completeness_vector(0.9, 2)))
+	plans, cats = [], []
+	for prim in parts:
+		c = [_hip.DeviceCatalogue(t['ra'], t['dec'], t['error'], dev) for t in (prim, tabs[1])]
+		plan, st = _hip.run_plan([c[0].n, c[1].n], type(params).from_buffer_copy(params), c, 200000, 200000, dev, lean=True)
+		assert int(st[_hip.ST_FLAGS]) == 0
+		plans.append(plan)
+		cats.append(c)
+	rows_alone = [int(p.read_status()[_hip.ST_ROWS]) for p in plans]
+	tables_alone = [[_hip.to_host(p.cols[c][:m]) for c in ('log_bf', 'p_any', 'p_i')] + [_hip.to_host(p.cols['idx'][1][:m])] for p, m in zip(plans, rows_alone)]
+	batch = _hip.ZoneBatch(plans)
+	for step in range(3):
+		batch.enqueue(cats)
+		assert batch.batched
+		for p, m, alone in zip(plans, rows_alone, tables_alone):
+			assert int(p.read_status()[_hip.ST_ROWS]) == m and int(p.read_status()[_hip.ST_FLAGS]) == 0
+			for got, want in zip([_hip.to_host(p.cols[c][:m]) for c in ('log_bf', 'p_any', 'p_i')] + [_hip.to_host(p.cols['idx'][1][:m])], alone):
+				np.testing.assert_array_equal(got, want)
+	# an ordinary enqueue of one of the plans in between (its scratch copies change parity against the other's): still one launch set, same tables
+	plans[1].enqueue(cats[1])
+	batch.enqueue(cats)
+	assert batch.batched
+	for p, m, alone in zip(plans, rows_alone, tables_alone):
+		assert int(p.read_status()[_hip.ST_ROWS]) == m and int(p.read_status()[_hip.ST_FLAGS]) == 0
+		np.testing.assert_array_equal(_hip.to_host(p.cols['p_i'][:m]), alone[2])
+	batch.close()
+	one = _hip.ZoneBatch(plans[:1])
+	one.enqueue(cats[:1])
+	assert not one.batched and int(plans[0].read_status()[_hip.ST_ROWS]) == rows_alone[0]
+	one.close()
+	for p in plans:
+		p.close()
