@@ -323,7 +323,7 @@ def job_bytes(sizes, error_columns, rows):
 	return b + (4 * k + 8 * (k * (k - 1) // 2) + 8 + 1 + 8 * 5 + 1) * rows
 
 
-def extra_configs(args, world, rank, device, dist, backend):
+def extra_configs(args, world, rank, device, dist, backend, records=None, only_jobs=None, t_start=None):
 	"""The jobs BASELINE names for several GPUs, measured in the SAME launch as the headline (whose default, weak scaling of
 	C3-S, is N x by construction): every job is FIXED in size and divided over the ranks, so value(N) / value(1) is its
 	strong-scaling curve.  One record per job, mode and carrier of the exchanges:
@@ -347,9 +347,11 @@ def extra_configs(args, world, rank, device, dist, backend):
 	only = os.environ.get('NWAY_BENCH_EXTRA_ONLY')
 	comms = ['torch'] + (['rccl'] if backend == 'nccl' else [])
 	steps, warm = min(args.steps, 20), min(max(args.warmup, 2), 5)
-	records = []
+	# (records: the caller's list, appended to record by record -- what has been measured is the caller's whatever happens later;
+	# only_jobs: this call's share of the list above; t_start: when the budget's clock started -- the calls of one run share it)
+	records = [] if records is None else records
 	budget_s = float(os.environ.get('NWAY_BENCH_EXTRA_BUDGET', '200'))  # the whole block is skipped job by job once this is spent
-	t_start = time.perf_counter()
+	t_start = time.perf_counter() if t_start is None else t_start
 
 	def agreed(ok):
 		"""the same decision on every rank (a rank that failed alone would leave the others in a collective)"""
@@ -358,6 +360,8 @@ def extra_configs(args, world, rank, device, dist, backend):
 		return bool(flag.item())
 	for name, mode, sizes, radius in jobs:
 		if only and name not in only.split(','):
+			continue
+		if only_jobs is not None and name not in only_jobs:
 			continue
 		if not agreed(time.perf_counter() - t_start < budget_s):
 			records.append(dict(job=name, skipped='time budget of the extra configurations (%g s) spent' % budget_s))
@@ -445,7 +449,7 @@ FIXED_JOBS = [('c3s', [1e5, 1e7], 5.0, 'BASELINE configs[2]: 2-way 1e5 x 1e7, 5 
 	('c5', [5e5, 1e8], 5.0, 'BASELINE configs[4]: 2-way 5e5 x 1e8, 5 arcsec')]
 
 
-def single_gpu_jobs(args, device, names, budget_s=240.0):
+def single_gpu_jobs(args, device, names, budget_s=240.0, out=None):
 	"""The fixed-size jobs BASELINE names, each as ONE job on ONE GPU (this process's): the N = 1 point of their strong-scaling
 	curves, measured in the same launch and on the same hardware as the N > 1 points of `extra_configs`, so that
 	value(N) / value(1) needs no second run.  Same generators, same seeds' family, same step definition (one pass of the whole
@@ -454,7 +458,7 @@ def single_gpu_jobs(args, device, names, budget_s=240.0):
 	import nway_amd
 	from nway_amd import _hip
 	scale = float(os.environ.get('NWAY_BENCH_EXTRA_SCALE', '1'))
-	out = {}
+	out = {} if out is None else out  # (the caller's dict: a job's record is the caller's as soon as it is measured)
 	t_start = time.perf_counter()
 	steps, warm = min(args.steps, 20), min(max(args.warmup, 2), 5)
 	for name, sizes, radius, what in FIXED_JOBS:
@@ -575,8 +579,10 @@ def main():
 		help='who carries the exchanges of the multi-GPU modes: torch.distributed (default) or the library\'s own RCCL calls behind the C ABI (nwayhip_comm_*)')
 	ap.add_argument('--extras', type=int, default=int(os.environ.get('NWAY_BENCH_EXTRAS', '1')),
 		help='N > 1: also measure, in the same launch, the fixed-size jobs BASELINE names for several GPUs (extra_configs: C3-S as one job, configs[3], configs[4]; both sharding modes, both carriers of the exchanges); 0 = skip')
-	ap.add_argument('--extras-watchdog', type=float, default=float(os.environ.get('NWAY_BENCH_EXTRAS_WATCHDOG', '480')),
-		help='N > 1: seconds after which a hung block of extra configurations is abandoned and the (already measured) headline printed')
+	ap.add_argument('--extras-watchdog', type=float, default=float(os.environ.get('NWAY_BENCH_EXTRAS_WATCHDOG', '0')),
+		help='N > 1: seconds after which hung supplementary blocks are abandoned and what has been measured is printed (0 = from their budgets: '
+		'200 s of extra configurations + 2 x 240 s of one-GPU references + 120 s for the job in flight when a budget runs out)')
+	ap.add_argument('--rendezvous-only', action='store_true', help='(tests) every rank joins the process group, rank 0 prints how many answered, nothing is measured')
 	ap.add_argument('--fixed-jobs', type=int, default=int(os.environ.get('NWAY_BENCH_FIXED_JOBS', '1')),
 		help='also measure, as ONE job on ONE GPU, the fixed-size jobs BASELINE names (configs[3], configs[4]; with N > 1 also configs[2]): '
 		'the N = 1 point of their strong-scaling curves, in this launch (rank 0, the other ranks wait); 0 = skip')
@@ -585,12 +591,52 @@ def main():
 	ap.add_argument('--streams', type=int, default=int(os.environ.get('NWAY_BENCH_STREAMS', '1')),
 		help='independent pipelines (own workspace, own output table, own HIP stream) the steps alternate over')
 	args = ap.parse_args()
+	if args.extras_watchdog <= 0:
+		args.extras_watchdog = float(os.environ.get('NWAY_BENCH_EXTRA_BUDGET', '200')) + 2 * 240.0 + 120.0
 
 	import torch
+
+	# `python bench.py --gpus N` without a launcher: this process becomes the launcher of N ranks (one per GPU, RCCL) -- the very command
+	# line the bench contract gives for N > 1.  With fewer than N GPUs (and the real backend) nothing sensible can be started: the one-GPU
+	# run goes ahead and its line says so in a top-level `error`.
+	spawn_note = None
+	if args.gpus > 1 and 'WORLD_SIZE' not in os.environ and os.environ.get('NWAY_BENCH_FORCE_DIST') != '1':
+		shared = os.environ.get('NWAY_BENCH_BACKEND', 'nccl') != 'nccl'   # (gloo: ranks may share a GPU -- functional tests)
+		have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+		if have >= args.gpus or shared:
+			import socket
+			import subprocess
+			with socket.socket() as sock:
+				sock.bind(('127.0.0.1', 0))
+				port = sock.getsockname()[1]
+			cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus), '--master-addr', '127.0.0.1',
+				'--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+			sys.stderr.write('bench.py: --gpus %d without a launcher: starting %s\n' % (args.gpus, ' '.join(cmd)))
+			sys.exit(subprocess.call(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))))
+		spawn_note = '--gpus %d asked for, %d GPU(s) visible: ONE rank ran (n_gpus below says 1)' % (args.gpus, have)
+		sys.stderr.write('bench.py: %s\n' % spawn_note)
+
+	world = int(os.environ.get('WORLD_SIZE', '1'))
+	if args.rendezvous_only:
+		import torch.distributed as dist
+		rank0 = int(os.environ.get('RANK', '0'))
+		seen = 1
+		if world > 1:
+			dist.init_process_group(os.environ.get('NWAY_BENCH_BACKEND', 'nccl'))
+			t = torch.ones(1, dtype=torch.int64)
+			if dist.get_backend() == 'nccl':
+				torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')) % max(torch.cuda.device_count(), 1))
+				t = t.cuda()
+			dist.all_reduce(t)
+			seen = int(t.item())
+			dist.destroy_process_group()
+		if rank0 == 0:
+			print(json.dumps(dict(rendezvous_only=True, gpus_asked=args.gpus, world=world, ranks_seen=seen, error=spawn_note)))
+		return
+
 	import nway_amd
 	from nway_amd import _hip
 
-	world = int(os.environ.get('WORLD_SIZE', '1'))
 	rank = int(os.environ.get('RANK', '0'))
 	local_rank = int(os.environ.get('LOCAL_RANK', '0'))
 	ngpu = max(torch.cuda.device_count(), 1)
@@ -613,7 +659,7 @@ def main():
 	tuning = None
 	if args.gpus != world:
 		if rank == 0:
-			sys.stderr.write('note: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE\n' % (args.gpus, world))
+			sys.stderr.write('note: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE (the line carries a top-level `error`)\n' % (args.gpus, world))
 	device = torch.device('cuda', (local_rank % ngpu) if world > 1 else 0)
 	torch.cuda.set_device(device)
 
@@ -682,7 +728,7 @@ def main():
 		# every step is a complete, independent pass; with --streams S the steps alternate over S
 		# pipelines (workspace + output table + HIP stream each) so that the latency-bound stages of
 		# one pass overlap the HBM-bound sweep of another
-		plans = [plan] + [_hip.MatchPlan(sizes, params, plan.cap_pairs, plan.cap_rows, device, lean=True) for _ in range(args.streams - 1)]
+		plans = [plan] + [_hip.MatchPlan(sizes, plan.params, plan.cap_pairs, plan.cap_rows, device, lean=True) for _ in range(args.streams - 1)]  # (plan.params: what the settling run ended up with)
 		from nway_amd import distributed as _ds
 		streams = _ds.side_streams(device, len(plans)) if len(plans) > 1 else [None]
 		counter = [0]
@@ -770,6 +816,8 @@ def main():
 		rows_per_step = engine.total_rows()
 	st = read_status()
 	assert int(st[_hip.ST_FLAGS]) == 0, 'overflow flags set: %d' % int(st[_hip.ST_FLAGS])
+	for pl in plans[1:]:  # (--streams > 1: the flags of every pipeline, not of the first alone)
+		assert int(pl.read_status()[_hip.ST_FLAGS]) == 0, 'overflow flags set on a sibling pipeline: %d' % int(pl.read_status()[_hip.ST_FLAGS])
 	ms_per_step = elapsed * 1e3 / args.steps
 
 	if rank == 0:
@@ -887,15 +935,36 @@ def main():
 		seen = torch.ones(1, dtype=torch.int64, device=device)
 		dist.all_reduce(seen)
 		ranks_seen = int(seen.item())
-	extras = None
-	n1 = None
+	extras = [] if (world > 1 or force_dist) and args.extras else None   # filled record by record
+	n1 = {} if args.fixed_jobs else None                                   # filled job by job
 	watchdog = None
 	multi = world > 1 or force_dist
+
+	def finish(aborted=None):
+		"""rank 0's line with everything measured so far; `aborted`: why the supplementary blocks did not run to their end"""
+		out['ranks_seen'] = ranks_seen
+		if args.gpus != world or ranks_seen != world:
+			out['error'] = '--gpus %d, WORLD_SIZE %d, ranks that answered the all-reduce: %d' % (args.gpus, world, ranks_seen)
+		if spawn_note:
+			out['error'] = (out.get('error', '') + '; ' if out.get('error') else '') + spawn_note
+		if extras is not None and (extras or aborted):
+			out['extra_configs'] = list(extras) + ([dict(error=aborted)] if aborted else [])
+		if aborted:
+			out['supplementary_aborted'] = aborted
+		if n1 or extras:
+			out['fixed_size_jobs'] = fixed_size_summary(extras, n1, world)
+			out['fixed_size_jobs_note'] = ('the jobs BASELINE names, fixed in size: `best` = the fastest of this launch\'s extra_configs records of the job over '
+				'%d GPU(s), `one_gpu` = the same job as one job on one GPU measured in this launch, `speedup_vs_one_gpu` their ratio (strong scaling); '
+				'the headline `value` above is %s' % (world, 'the weak-scaling run the bench contract asks for (per-GPU work fixed), N x by construction'
+				if (world > 1 and not strong) else 'the one-GPU run of configs[2]'))
+		sys.stdout.write(json.dumps(out) + '\n')
+		sys.stdout.flush()
+
 	if multi and (args.extras or args.fixed_jobs):
 		# The blocks below (fixed-size jobs in several multi-GPU modes, the one-GPU references) run collectives that no machine
 		# with more than one GPU has executed yet.  The headline above is measured: whatever happens to them -- a hang, an error on
-		# one rank -- it must still come out.  After --extras-watchdog seconds the other ranks leave and rank 0 prints the line as it
-		# stands; an exception in the blocks does the same at once.
+		# one rank -- it must still come out, and so must every record of theirs that was finished by then.  After --extras-watchdog
+		# seconds the other ranks leave and rank 0 prints the line as it stands; an exception in the blocks does the same at once.
 		import threading
 		import traceback
 		once = threading.Lock()
@@ -905,59 +974,57 @@ def main():
 				time.sleep(60)  # (the other thread is printing; it ends the process)
 				return
 			if rank == 0:
-				out['ranks_seen'] = ranks_seen
-				out['extra_configs'] = [dict(error=reason)]
-				sys.stdout.write(json.dumps(out) + '\n')
-				sys.stdout.flush()
+				finish(aborted=reason)
 			os._exit(0)
 		watchdog = threading.Timer(args.extras_watchdog + (2.0 if rank == 0 else 0.0), give_up,
-			['the extra configurations did not finish within %g s: the watchdog printed the headline and ended the run' % args.extras_watchdog])
+			['the supplementary blocks did not finish within %g s: the watchdog printed what had been measured and ended the run' % args.extras_watchdog])
 		watchdog.daemon = True
 		watchdog.start()
 	try:
-		if multi and args.extras:
-			# (every rank takes part; the headline's engine has been measured and is released first)
-			if engine is not None:
-				if getattr(engine, 'plan', None) is not None:
-					engine.plan.close()
-				engine = None
-				plan = None
-				plans = []
-				torch.cuda.empty_cache()
-			extras = extra_configs(args, world, rank, device, dist, backend)
-		if args.fixed_jobs and ((multi and args.extras) or (not multi and args.cpu_sample != 0)):
-			# (with N > 1 they belong to the extra_configs block; a profiling / A-B invocation -- --cpu-sample 0 on one GPU -- measures the headline only)
+		run_fixed = args.fixed_jobs and ((multi and args.extras) or (not multi and args.cpu_sample != 0))
+		# (with N > 1 the one-GPU references belong to the extra_configs block; a profiling / A-B invocation -- --cpu-sample 0 on one GPU -- measures the headline only)
+		if (multi and args.extras) or run_fixed:
+			# (the headline's engine has been measured and is released first)
 			if engine is not None and getattr(engine, 'plan', None) is not None:
 				engine.plan.close()
 			engine = None
-			if not multi:
+			if not multi or args.extras:
 				for pl in plans:
-					pl.close()
+					if pl is not None and getattr(pl, 'handle', None):
+						pl.close()
 				plans, plan = [], None
 				cats = sec_copies = None
 			torch.cuda.empty_cache()
-			if rank == 0:
-				n1 = single_gpu_jobs(args, device, ['c4s', 'c5'] + (['c3s'] if multi else []))
-			if multi:
-				dist.barrier()  # (the other ranks wait here while rank 0 measures the one-GPU references)
+
+		def one_gpu(names):
+			if run_fixed:
+				if rank == 0:
+					single_gpu_jobs(args, device, names, out=n1)
+				if multi:
+					dist.barrier()  # (the other ranks wait here while rank 0 measures the one-GPU references)
+		# Order = what a first run on N GPUs must not lose to a time budget: the two jobs the north star names for N GPUs
+		# (configs[4] by declination zones, configs[3] by primary rows), then THEIR one-GPU references, then the other modes
+		# and carriers, then the remaining reference.
+		first = ['c5_zones', 'c4s_rows']
+		t_extras = time.perf_counter()
+		if multi and args.extras:
+			extra_configs(args, world, rank, device, dist, backend, records=extras, only_jobs=first, t_start=t_extras)
+		spent_first = time.perf_counter() - t_extras
+		one_gpu(['c5', 'c4s'])
+		if multi and args.extras:
+			# (one budget for both calls; the one-GPU references in between have their own)
+			extra_configs(args, world, rank, device, dist, backend, records=extras, only_jobs=['c5_rows', 'c3s_split', 'c5_split', 'c3s_zones', 'c4s_zones'],
+				t_start=time.perf_counter() - spent_first)
+			one_gpu(['c3s'])
 	except Exception as e:
 		if watchdog is None:
 			raise
 		traceback.print_exc()
-		give_up('the extra configurations ended with %s: %s (rank %d); the headline above was measured before them' % (type(e).__name__, e, rank))
+		give_up('the supplementary blocks ended with %s: %s (rank %d); the headline and the records above were measured before that' % (type(e).__name__, e, rank))
 	if watchdog is not None:
 		watchdog.cancel()
 	if rank == 0:
-		out['ranks_seen'] = ranks_seen
-		if extras is not None:
-			out['extra_configs'] = extras
-		if n1 is not None or extras is not None:
-			out['fixed_size_jobs'] = fixed_size_summary(extras, n1, world)
-			out['fixed_size_jobs_note'] = ('the jobs BASELINE names, fixed in size: `best` = the fastest of this launch\'s extra_configs records of the job over '
-				'%d GPU(s), `one_gpu` = the same job as one job on one GPU measured in this launch, `speedup_vs_one_gpu` their ratio (strong scaling); '
-				'the headline `value` above is %s' % (world, 'the weak-scaling run the bench contract asks for (per-GPU work fixed), N x by construction'
-				if (world > 1 and not strong) else 'the one-GPU run of configs[2]'))
-		print(json.dumps(out))
+		finish()
 	if world > 1 or force_dist:
 		dist.destroy_process_group()
 

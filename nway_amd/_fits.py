@@ -229,7 +229,17 @@ def _string_cards(key, value):
 	text = str(value).replace("'", "''")
 	if len(text) <= 68:
 		return [_card(key, value)]
-	pieces = [text[i:i + 67] for i in range(0, len(text), 67)]
+	# pieces of at most 67 characters, none ending inside an escaped quote: a piece that ends in an odd run of quotes would leave
+	# "...'&'" on its card and "'..." on the next -- a reader (this one, astropy) ends the string at the lone quote
+	pieces, at = [], 0
+	while at < len(text):
+		end = min(at + 67, len(text))
+		if end < len(text):
+			run = len(text[at:end]) - len(text[at:end].rstrip("'"))
+			if run % 2 == 1:
+				end -= 1
+		pieces.append(text[at:end])
+		at = end
 	cards = []
 	for n, piece in enumerate(pieces):
 		body = "'%s%s'" % (piece, '&' if n + 1 < len(pieces) else '')
@@ -330,7 +340,7 @@ def write_table(filename, columns, extname, primary_header=None, table_header=No
 		if name in tzero:
 			tcards.append(_card('TZERO%d' % i, tzero[name]))
 	for k, v in (table_header or {}).items():
-		tcards.append(_card(k, v))
+		tcards += _string_cards(k, v) if isinstance(v, str) else [_card(k, v)]  # (a long string: CONTINUE cards, as in the primary header)
 	raw = data.tobytes()
 	with open(filename, 'wb') as f:
 		f.write(_header_bytes(pcards))

@@ -398,6 +398,7 @@ class ShardedMatch(MagnitudePriors):
 			self.plan, self.status = None, numpy.zeros(_hip.STATUS_WORDS, dtype=numpy.int64)
 			return
 		self.plan, self.status = _hip.run_plan(sizes, self.params, self.cats, cap_pairs, cap_rows, self.device, lean=True)
+		self.params = self.plan.params  # (what the run settled on: slots, table size, path -- not the request)
 
 	# -- per batch -----------------------------------------------------------------------
 	def step(self, cats=None):

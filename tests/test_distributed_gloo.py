@@ -322,3 +322,27 @@ def test_sharded_magnitude_priors_on_every_catalogue_golden(tmp_path):
 	assert_table_matches(t, g, 'rad_', ['P', 'A', 'B'], rtol=1e-9, atol=1e-13)
 	for b in ('bias_P_F', 'bias_A_M', 'bias_B_M'):
 		np.testing.assert_allclose(t[b], g['rad_' + b], rtol=1e-9, err_msg=b)
+
+
+def test_bench_plain_form_starts_the_ranks_itself():
+	"""`python bench.py --gpus N` without a launcher and without WORLD_SIZE (round 6): bench.py becomes the launcher of N ranks
+	(torch.distributed.run, 127.0.0.1) instead of running one GPU -- here over gloo and only as far as the rendezvous (no GPU):
+	rank 0 reports how many ranks answered; with the real backend and fewer GPUs than ranks the one-rank run says so in `error`"""
+	import json
+	import subprocess
+	bench = os.path.join(ROOT, 'bench.py')
+	env = dict(os.environ, NWAY_BENCH_BACKEND='gloo')
+	env.pop('WORLD_SIZE', None)
+	env.pop('RANK', None)
+	res = subprocess.run([sys.executable, bench, '--gpus', '3', '--rendezvous-only'], stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True,
+		timeout=300, env=env, cwd=ROOT)
+	assert res.returncode == 0, res.stderr[-2000:]
+	out = json.loads([l for l in res.stdout.splitlines() if l.startswith('{')][-1])
+	assert out['world'] == 3 and out['ranks_seen'] == 3 and out['gpus_asked'] == 3 and out['error'] is None
+	assert 'torch.distributed.run' in res.stderr and '--nproc-per-node 3' in res.stderr
+	if not torch.cuda.is_available():
+		env['NWAY_BENCH_BACKEND'] = 'nccl'
+		res = subprocess.run([sys.executable, bench, '--gpus', '2', '--rendezvous-only'], stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True,
+			timeout=300, env=env, cwd=ROOT)
+		out = json.loads([l for l in res.stdout.splitlines() if l.startswith('{')][-1])
+		assert out['world'] == 1 and 'GPU(s) visible' in out['error']

@@ -178,3 +178,18 @@ def test_signed_byte_columns_keep_their_type(tmp_path):
 	np.testing.assert_array_equal(t.data['u'], np.arange(5) * 60)
 	assert t.header['TZERO1'] == -128 and 'TZERO2' not in t.header
 	assert t.formats == ['B', 'B']
+
+
+def test_long_string_values_with_quotes_at_the_cut_round_trip(tmp_path):
+	"""a header value longer than a card goes out over CONTINUE cards in pieces of 67 characters; an escaped quote ('') must not
+	straddle a cut -- "...'&'" on one card and "'..." on the next end the string at the lone quote for every reader (found by the
+	advisor, round 5): quotes at every offset around the cut come back as written"""
+	for offset in range(60, 72):
+		for quotes in ("'", "''", "'''"):
+			text = 'x' * offset + quotes + 'y' * 90 + "'" + 'z' * 70
+			f = str(tmp_path / ('q%d_%d.fits' % (offset, len(quotes))))
+			_fits.write_table(f, [('ID', 'J', np.arange(3))], 'T', primary_header={'NWAYCMD': text}, table_header={'INPUT': text[::-1]})
+			assert _fits.read_header(f, 0)['NWAYCMD'] == text, (offset, quotes)
+			assert _fits.read_header(f, 1)['INPUT'] == text[::-1], (offset, quotes)
+			raw = open(f, 'rb').read()
+			assert len(raw) % 2880 == 0

@@ -348,16 +348,18 @@ def test_bench_eight_gloo_ranks_share_the_gpu(tmp_path):
 	fixed-size summary with the one-GPU references rank 0 measures in the same launch"""
 	env = dict(os.environ, NWAY_BENCH_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0', NWAY_BENCH_EXTRA_SCALE='0.02',
 		NWAY_BENCH_EXTRA_ONLY='c5_zones,c4s_rows,c3s_split')
-	cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '8', '--master-addr', '127.0.0.1',
-		'--master-port', str(free_port()), os.path.join(ROOT, 'bench.py'), '--gpus', '8', '--steps', '4', '--warmup', '2', '--prewarm', '3',
+	# (round 6: the PLAIN form `python bench.py --gpus 8`, no launcher and no WORLD_SIZE -- bench.py starts the eight ranks itself)
+	env.pop('WORLD_SIZE', None)
+	cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '8', '--steps', '4', '--warmup', '2', '--prewarm', '3',
 		'--n-primary', '5000', '--n-secondary', '800000']
 	res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, timeout=1200, env=env, cwd=ROOT)
 	assert res.returncode == 0, res.stderr[-3000:]
 	line = [l for l in res.stdout.splitlines() if l.startswith('{')][-1]
 	out = json.loads(line)
-	assert out['n_gpus'] == 8 and out['ranks_seen'] == 8 and out['scaling'] == 'weak'
+	assert out['n_gpus'] == 8 and out['ranks_seen'] == 8 and out['scaling'] == 'weak' and 'error' not in out and 'supplementary_aborted' not in out
 	assert 8 * 5000 * 1.7 < out['config']['rows_per_step'] < 8 * 5000 * 1.9
 	recs = out['extra_configs']
+	assert [r['job'] for r in recs][:2] == ['c5_zones', 'c4s_rows'], 'the two jobs the north star names for N GPUs are measured first'
 	assert sorted(r['job'] for r in recs) == ['c3s_split', 'c4s_rows', 'c5_zones']
 	for r in recs:
 		assert 'error' not in r and r['ranks_seen'] == 8 and r['n_gpus'] == 8 and r['flags'] == 0 and r['value'] > 0, r
@@ -386,9 +388,12 @@ def test_bench_headline_survives_hung_extras(tmp_path):
 	assert len(lines) == 1
 	out = json.loads(lines[0])
 	assert out['n_gpus'] == 2 and out['ranks_seen'] == 2 and out['value'] > 0 and out['ms_per_step'] > 0
-	# (either rank 0's own timer, or the broken collective it was in when the other rank left)
-	err = out['extra_configs'][0]['error']
-	assert 'watchdog' in err or 'measured before them' in err, err
+	# (either rank 0's own timer, or the broken collective it was in when the other rank left); the abort is flagged at the top level,
+	# and whatever records were finished by then stand in front of the error record
+	err = out['extra_configs'][-1]['error']
+	assert 'watchdog' in err or 'measured before that' in err, err
+	assert out['supplementary_aborted'] == err
+	assert all('error' not in r for r in out['extra_configs'][:-1])
 
 
 def mag_worker(rank, world, port, outfile, mode):
