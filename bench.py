@@ -316,6 +316,46 @@ def live_traffic(argv_tail, n_secondary, budget_s=150.0):
 		% (vals['FETCH_SIZE'], vals['WRITE_SIZE'], time.perf_counter() - t0)), detail
 
 
+# FP64 vector peak of the part: 256 CUs x 4 SIMDs x 16 FP64 lanes per clock x 2 flops (FMA) x 2.4 GHz (half the FP32 vector rate of
+# MI355X_MICROARCH.md, 157.3 TFLOP/s spec; SURVEY.md 8d: "FP64 vector ALU, ~79 TFLOP/s nominal")
+FP64_PEAK_TFLOPS = 78.6
+# FP64 flops (an FMA counts two) of the elementary functions as csrc/fastmath.inc evaluates them on their short roads, counted off the
+# source: sincos 49, x/180*pi 6, atan2 25 and hypot 14 (a division and a square root at ~10 each), log 46, log10 56, 10^x 34
+FLOPS_TEST = 135.0   # one distance test: the trig-free bound (~15), radians of both longitudes, ONE sincos (the longitude difference), the
+                     # Vincenty numerators and denominator (~16), hypot, atan2, degrees and arc seconds (fastskymatch.py:36-47)
+FLOPS_POINT = 55.0   # sin / cos of a latitude, once per primary (registration) and once per link (routing)
+FLOPS_GROUP = 146.0  # per primary: two log10 and one 10^x of the log-sum-exp (__init__.py:423-457)
+
+
+def flops_row(n_present):
+	"""a row with n_present catalogues (bayesdistance.py:64-86 + :26-32 + its two terms of the group statistics): n weights s**-2 and
+	their logarithms, log of their sum, three operations per pair, two divisions, posterior (10^x, a division), p_i and the LSE term (2 x 10^x)"""
+	n = float(n_present)
+	return 0.0 if n < 2 else 57.0 * n + 117.0 + 1.5 * n * (n - 1) + 68.0
+
+
+def alu_model(k, n_primary, rows, tests, ms):
+	"""The FP64 roofline beside the HBM one ("report both rooflines honestly"): algorithmic FP64 flops of a pass --
+	distance tests, latitudes, rows, group statistics as counted above; a row with a counterpart is taken to hold (2 + k) / 2
+	catalogues for k >= 3 (the status words do not count rows by ncat) -- over the pass time, against the FP64 vector peak."""
+	links = max(rows - n_primary, 0)
+	n_bar = 2.0 if k == 2 else (2.0 + k) / 2.0
+	flops = tests * FLOPS_TEST + (n_primary + links) * FLOPS_POINT + n_primary * FLOPS_GROUP + links * flops_row(n_bar)
+	tf = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+	return dict(fp64_flops=flops, achieved=tf, peak=FP64_PEAK_TFLOPS, unit='TFLOP/s', frac=tf / FP64_PEAK_TFLOPS,
+		model='tests x %g + (primaries + links) x %g + primaries x %g + rows with a counterpart x %g flops (bench.py: alu_model)' % (FLOPS_TEST, FLOPS_POINT, FLOPS_GROUP, flops_row(n_bar)))
+
+
+def bound_of(pass_frac, alu_frac):
+	"""what a pass is bound by, from its two roofline fractions: neither above a fifth = the chains of dependent round trips and the
+	launch boundaries of its kernels, not a throughput of the machine"""
+	if pass_frac >= 0.2 and pass_frac >= alu_frac:
+		return 'hbm'
+	if alu_frac >= 0.2:
+		return 'fp64'
+	return 'latency (launch boundaries + dependent round trips + FP64 chains at 1-2 waves per SIMD: neither roofline above 0.2)'
+
+
 def job_bytes(sizes, error_columns, rows):
 	"""algorithmic bytes of a whole JOB: every input column once, every output column once"""
 	k = len(sizes)
@@ -496,6 +536,8 @@ def single_gpu_jobs(args, device, names, budget_s=240.0, out=None):
 			jb = job_bytes(sizes, [True] + [False] * (k - 1), rows)
 			rec.update(ms_per_step=ms, steps=steps, rows=rows, value=rows / (ms * 1e-3), flags=int(st[_hip.ST_FLAGS]), job_bytes=jb,
 				pass_frac=jb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, path=plan.description)
+			rec['alu'] = alu_model(k, sizes[0], rows, int(st[_hip.ST_TESTS]), ms)
+			rec['bound'] = bound_of(rec['pass_frac'], rec['alu']['frac'])
 			if name == 'c5' and os.environ.get('NWAY_BENCH_LOCAL_ZONES', '1') != '0':
 				# the same job with the catalogues bucketed into declination zones at set-up (ZoneShardedMatch on ONE rank, round 5): every
 				# zone's cell table fits the LDS of a sweep workgroup, where the job as one zone needs the large-table sweep; round 6: the
@@ -517,7 +559,8 @@ def single_gpu_jobs(args, device, names, budget_s=240.0, out=None):
 					torch.cuda.synchronize(device)
 					msz = (time.perf_counter() - t0) * 1e3 / steps
 					stz = eng.read_status()
-					rec['zones'] = dict(zones=8, one_launch_set=bool(eng.batched), ms_per_step=msz, rows=int(stz[_hip.ST_ROWS]), value=int(stz[_hip.ST_ROWS]) / (msz * 1e-3), flags=int(stz[_hip.ST_FLAGS]),
+					alz = alu_model(k, sizes[0], int(stz[_hip.ST_ROWS]), int(stz[_hip.ST_TESTS]), msz)
+					rec['zones'] = dict(zones=8, one_launch_set=bool(eng.batched), alu=alz, bound=bound_of(jb / (msz * 1e-3) / 1e9 / HBM_PEAK_GBS, alz['frac']), ms_per_step=msz, rows=int(stz[_hip.ST_ROWS]), value=int(stz[_hip.ST_ROWS]) / (msz * 1e-3), flags=int(stz[_hip.ST_FLAGS]),
 						pass_frac=jb / (msz * 1e-3) / 1e9 / HBM_PEAK_GBS, setup_s=eng.setup_seconds,
 						note='ZoneShardedMatch(zones_per_rank=8) on one rank, the zones of a step as one launch set: the one-time bucketing of the catalogues by zone is set-up, like the exchanges of the multi-GPU modes')
 				finally:
@@ -543,7 +586,7 @@ def fixed_size_summary(extras, n1, world):
 		one = (n1 or {}).get(name)
 		entry = dict(job=what)
 		if one is not None:
-			entry['one_gpu'] = dict((key, one.get(key)) for key in ('ms_per_step', 'value', 'rows', 'pass_frac', 'error', 'skipped') if key in one)
+			entry['one_gpu'] = dict((key, one.get(key)) for key in ('ms_per_step', 'value', 'rows', 'pass_frac', 'alu', 'bound', 'error', 'skipped') if key in one)
 			if one.get('zones'):
 				entry['one_gpu_zones'] = one['zones']
 		if best is not None:

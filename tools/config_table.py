@@ -11,6 +11,8 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # (the FP64 model beside the byte model: bench.alu_model)
 CONFIGS = [
 	('C3-S 2-way 1e5 x 1e7, uniform sky, 5"', ['c3s'], 2, [100000, 10000000]),
 	('C3-D 2-way 1e5 x 1e7, 6 deg^2 patch (flat cells), 5"', ['c3d'], 2, [100000, 10000000]),
@@ -21,8 +23,8 @@ CONFIGS = [
 	("C1' BASELINE configs[0] stand-in: real COSMOS_XMM 1 797 x seeded OPT 560 536, 2 deg^2, 20\"", ['c1x'], 2, [1797, 560536]),
 	("C2' BASELINE configs[1] stand-in: the same x seeded IRAC 345 512 (3-way), 20\"", ['c2x'], 3, [1797, 560536, 345512]),
 ]
-print('| configuration | path | rows M | distance tests | us per pass | rows/s | B_alg (MB) | B_alg / t (GB/s) | of 8 TB/s | stages (us, each bracketed by events) |')
-print('|---|---|---|---|---|---|---|---|---|---|')
+print('| configuration | path | rows M | distance tests | us per pass | rows/s | B_alg (MB) | B_alg / t (GB/s) | of 8 TB/s | FP64 model (Mflop) | of %g TFLOP/s | bound | stages (us, each bracketed by events) |' % bench.FP64_PEAK_TFLOPS)
+print('|---|---|---|---|---|---|---|---|---|---|---|---|---|')
 for name, args, k, sizes in CONFIGS:
 	out = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'status_probe.py')] + args, stdout=subprocess.PIPE,
 		stderr=subprocess.STDOUT, universal_newlines=True).stdout
@@ -32,11 +34,13 @@ for name, args, k, sizes in CONFIGS:
 	plan = re.search(r'plan: (.*)', out)
 	stages = re.search(r'stages us/step: (.*?) \|', out)
 	if not st or not tot:
-		print('| %s | failed | | | | | | | | |' % name)
+		print('| %s | failed | | | | | | | | | | | |' % name)
 		sys.stderr.write(out)
 		continue
 	rows, tests, us = int(st.group(1)), int(st.group(4)), float(tot.group(1))
 	b_alg = 24.0 * sizes[0] + 16.0 * sum(sizes[1:]) + (66.0 if k == 2 else 94.0) * rows
 	rate = b_alg / (us * 1e-6) / 1e9
-	print('| %s | %s | %d | %d | %.1f | %.3g | %.1f | %.0f | %.2f | %s |' % (name, (path.group(1) if path else '?') + (' (%s)' % ' '.join(x for x in plan.group(1).split() if x.split('=')[0] in ('sweep', 'tail', 'link_slots', 'direct_log2')) if plan else ''), rows, tests, us, rows / (us * 1e-6), b_alg / 1e6, rate, rate / 8000.,
+	alu = bench.alu_model(k, sizes[0], rows, tests, us * 1e-3)
+	print('| %s | %s | %d | %d | %.1f | %.3g | %.1f | %.0f | %.2f | %.0f | %.3f | %s | %s |' % (name, (path.group(1) if path else '?') + (' (%s)' % ' '.join(x for x in plan.group(1).split() if x.split('=')[0] in ('sweep', 'tail', 'link_slots', 'direct_log2')) if plan else ''), rows, tests, us, rows / (us * 1e-6), b_alg / 1e6, rate, rate / 8000.,
+		alu['fp64_flops'] / 1e6, alu['frac'], bench.bound_of(rate / 8000., alu['frac']).split(' (')[0],
 		' '.join(x for x in (stages.group(1) if stages else '').split() if not x.endswith('=0.0'))))
