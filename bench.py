@@ -363,7 +363,7 @@ def job_bytes(sizes, error_columns, rows):
 	return b + (4 * k + 8 * (k * (k - 1) // 2) + 8 + 1 + 8 * 5 + 1) * rows
 
 
-def extra_configs(args, world, rank, device, dist, backend, records=None, only_jobs=None, t_start=None):
+def extra_configs(args, world, rank, device, dist, backend, records=None, only_jobs=None, t_start=None, deadline=None):
 	"""The jobs BASELINE names for several GPUs, measured in the SAME launch as the headline (whose default, weak scaling of
 	C3-S, is N x by construction): every job is FIXED in size and divided over the ranks, so value(N) / value(1) is its
 	strong-scaling curve.  One record per job, mode and carrier of the exchanges:
@@ -403,7 +403,7 @@ def extra_configs(args, world, rank, device, dist, backend, records=None, only_j
 			continue
 		if only_jobs is not None and name not in only_jobs:
 			continue
-		if not agreed(time.perf_counter() - t_start < budget_s):
+		if not agreed(time.perf_counter() - t_start < budget_s and (deadline is None or time.perf_counter() < deadline)):
 			records.append(dict(job=name, skipped='time budget of the extra configurations (%g s) spent' % budget_s))
 			continue
 		local = [distributed.shard_bounds(n, world) for n in sizes]
@@ -489,7 +489,7 @@ FIXED_JOBS = [('c3s', [1e5, 1e7], 5.0, 'BASELINE configs[2]: 2-way 1e5 x 1e7, 5 
 	('c5', [5e5, 1e8], 5.0, 'BASELINE configs[4]: 2-way 5e5 x 1e8, 5 arcsec')]
 
 
-def single_gpu_jobs(args, device, names, budget_s=240.0, out=None):
+def single_gpu_jobs(args, device, names, budget_s=240.0, out=None, deadline=None):
 	"""The fixed-size jobs BASELINE names, each as ONE job on ONE GPU (this process's): the N = 1 point of their strong-scaling
 	curves, measured in the same launch and on the same hardware as the N > 1 points of `extra_configs`, so that
 	value(N) / value(1) needs no second run.  Same generators, same seeds' family, same step definition (one pass of the whole
@@ -504,8 +504,8 @@ def single_gpu_jobs(args, device, names, budget_s=240.0, out=None):
 	for name, sizes, radius, what in FIXED_JOBS:
 		if name not in names:
 			continue
-		if time.perf_counter() - t_start > budget_s:
-			out[name] = dict(skipped='time budget of the single-GPU references (%g s) spent' % budget_s)
+		if time.perf_counter() - t_start > budget_s or (deadline is not None and time.perf_counter() > deadline):
+			out[name] = dict(skipped='time budget of the single-GPU references (%g s) or of the supplementary blocks spent' % budget_s)
 			continue
 		sizes = [max(int(n * scale), 8) for n in sizes]
 		rec = dict(job=what, sizes=sizes, radius_arcsec=radius, n_gpus=1)
@@ -623,8 +623,8 @@ def main():
 	ap.add_argument('--extras', type=int, default=int(os.environ.get('NWAY_BENCH_EXTRAS', '1')),
 		help='N > 1: also measure, in the same launch, the fixed-size jobs BASELINE names for several GPUs (extra_configs: C3-S as one job, configs[3], configs[4]; both sharding modes, both carriers of the exchanges); 0 = skip')
 	ap.add_argument('--extras-watchdog', type=float, default=float(os.environ.get('NWAY_BENCH_EXTRAS_WATCHDOG', '0')),
-		help='N > 1: seconds after which hung supplementary blocks are abandoned and what has been measured is printed (0 = from their budgets: '
-		'200 s of extra configurations + 2 x 240 s of one-GPU references + 120 s for the job in flight when a budget runs out)')
+		help='N > 1: seconds after which hung supplementary blocks are abandoned and what has been measured is printed (0 = from their budget: '
+		'NWAY_BENCH_SUPP_BUDGET, 330 s, after which no further job starts, + 120 s for the job in flight)')
 	ap.add_argument('--rendezvous-only', action='store_true', help='(tests) every rank joins the process group, rank 0 prints how many answered, nothing is measured')
 	ap.add_argument('--fixed-jobs', type=int, default=int(os.environ.get('NWAY_BENCH_FIXED_JOBS', '1')),
 		help='also measure, as ONE job on ONE GPU, the fixed-size jobs BASELINE names (configs[3], configs[4]; with N > 1 also configs[2]): '
@@ -634,8 +634,11 @@ def main():
 	ap.add_argument('--streams', type=int, default=int(os.environ.get('NWAY_BENCH_STREAMS', '1')),
 		help='independent pipelines (own workspace, own output table, own HIP stream) the steps alternate over')
 	args = ap.parse_args()
+	# ONE budget for everything after the headline (N > 1): no job of the supplementary blocks starts once it is spent; the watchdog
+	# allows the job then in flight two more minutes
+	supp_budget = float(os.environ.get('NWAY_BENCH_SUPP_BUDGET', '330'))
 	if args.extras_watchdog <= 0:
-		args.extras_watchdog = float(os.environ.get('NWAY_BENCH_EXTRA_BUDGET', '200')) + 2 * 240.0 + 120.0
+		args.extras_watchdog = supp_budget + 120.0
 
 	import torch
 
@@ -1039,10 +1042,12 @@ def main():
 				cats = sec_copies = None
 			torch.cuda.empty_cache()
 
+		deadline = (time.perf_counter() + supp_budget) if multi else None
+
 		def one_gpu(names):
 			if run_fixed:
 				if rank == 0:
-					single_gpu_jobs(args, device, names, out=n1)
+					single_gpu_jobs(args, device, names, out=n1, deadline=deadline)
 				if multi:
 					dist.barrier()  # (the other ranks wait here while rank 0 measures the one-GPU references)
 		# Order = what a first run on N GPUs must not lose to a time budget: the two jobs the north star names for N GPUs
@@ -1051,13 +1056,13 @@ def main():
 		first = ['c5_zones', 'c4s_rows']
 		t_extras = time.perf_counter()
 		if multi and args.extras:
-			extra_configs(args, world, rank, device, dist, backend, records=extras, only_jobs=first, t_start=t_extras)
+			extra_configs(args, world, rank, device, dist, backend, records=extras, only_jobs=first, t_start=t_extras, deadline=deadline)
 		spent_first = time.perf_counter() - t_extras
 		one_gpu(['c5', 'c4s'])
 		if multi and args.extras:
 			# (one budget for both calls; the one-GPU references in between have their own)
 			extra_configs(args, world, rank, device, dist, backend, records=extras, only_jobs=['c5_rows', 'c3s_split', 'c5_split', 'c3s_zones', 'c4s_zones'],
-				t_start=time.perf_counter() - spent_first)
+				t_start=time.perf_counter() - spent_first, deadline=deadline)
 			one_gpu(['c3s'])
 	except Exception as e:
 		if watchdog is None:

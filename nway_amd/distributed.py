@@ -1048,7 +1048,8 @@ class ZoneShardedMatch(MagnitudePriors):
 			self._build_zone(z)
 		self._streams = None
 		if self._batch is not None:
-			self._batch.close()
+			for b, _ in self._batch:
+				b.close()
 			self._batch = None
 		z0 = self.zones[0]
 		self.plan, self.cats, self.empty, self.status = z0['plan'], z0['cats'], all(z['empty'] for z in self.zones), z0['status']
@@ -1076,12 +1077,28 @@ class ZoneShardedMatch(MagnitudePriors):
 		live = [z for z in self.zones if not z['empty']]
 		if cats is not None and len(self.zones) > 1:
 			raise ValueError('ZoneShardedMatch.step(cats=...) stands for the catalogues of ONE zone: this rank holds %d' % len(self.zones))
-		if len(live) > 1 and self.nstreams == 1 and self.one_launch:
+		if len(live) > 1 and self.one_launch:
 			from nway_amd import _hip
+			import torch
+			# one launch set -- or, ``streams`` > 1, that many launch sets of consecutive zones on streams of their own: the
+			# registration of one set (bound by memory-side atomics, a wave per SIMD) then runs beside the sweep of another
+			ngroups = min(self.nstreams, len(live) // 2) if self.nstreams > 1 else 1
 			if self._batch is None:
-				self._batch = _hip.ZoneBatch([z['plan'] for z in live])
-			self._batch.enqueue([z['cats'] for z in live])
-			self.batched = self._batch.batched
+				bounds = [len(live) * g // max(ngroups, 1) for g in range(max(ngroups, 1) + 1)]
+				self._batch = [(_hip.ZoneBatch([z['plan'] for z in live[lo:hi]]), [z['cats'] for z in live[lo:hi]]) for lo, hi in zip(bounds[:-1], bounds[1:])]
+			if len(self._batch) == 1:
+				self._batch[0][0].enqueue(self._batch[0][1])
+			else:
+				if self._streams is None:
+					self._streams = side_streams(self.device, len(self._batch))
+				cur = torch.cuda.current_stream(self.device)
+				for st in self._streams:
+					st.wait_stream(cur)
+				for (batch, cats_of), st in zip(self._batch, self._streams):
+					batch.enqueue(cats_of, stream=ctypes_stream(st))
+				for st in self._streams:
+					cur.wait_stream(st)
+			self.batched = all(b.batched for b, _ in self._batch)
 			return
 		if len(live) <= 1 or self.nstreams == 1:
 			for z in live:
@@ -1135,7 +1152,8 @@ class ZoneShardedMatch(MagnitudePriors):
 
 	def close(self):
 		if getattr(self, '_batch', None) is not None:
-			self._batch.close()
+			for b, _ in self._batch:
+				b.close()
 			self._batch = None
 		for z in self.zones:
 			if z.get('plan') is not None:
