@@ -271,7 +271,17 @@ int nwayhip_zones_create(nwayhip_zones** zones, nwayhip_plan* const* h_plans, in
 int nwayhip_zones_destroy(nwayhip_zones* zones);
 size_t nwayhip_zones_args_bytes(const nwayhip_zones* zones);
 int nwayhip_zones_enqueue(nwayhip_zones* zones, const nwayhip_zone_run* h_runs /*[nplans]*/, void* d_args, size_t d_args_bytes, void* stream);
+/* 0: the last enqueue went out zone by zone; 1: as one launch set; 2: as one launch set whose registration was owner-computes */
 int32_t nwayhip_zones_batched(const nwayhip_zones* zones);
+/* How a launch set registers its primaries in their cell tables (fastskymatch.py:118-133, "only the primary catalogue is allowed
+ * to define new buckets").  ATOMICS: every registration claims its table position with an atomic in memory, as a plan of its own
+ * does.  OWNER: no atomic per registration -- the registrations are sorted into the slices of their tables and every slice has one
+ * workgroup that claims in LDS (two launches; csrc/zones.inc) -- what pays once the atomics are a throughput: AUTO (the default)
+ * takes it from 200 000 primaries per launch set on.  The tables obey the same invariants either way, the results are the same. */
+#define NWAYHIP_ZONES_REG_AUTO 0
+#define NWAYHIP_ZONES_REG_ATOMICS 1
+#define NWAYHIP_ZONES_REG_OWNER 2
+int nwayhip_zones_set_registration(nwayhip_zones* zones, int32_t mode);
 
 /* ---- secondary-split mode: several GPUs on ONE job ---------------------------------------
  * (second half; the reference is a single process.)  Every rank registers ALL

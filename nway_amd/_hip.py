@@ -109,6 +109,7 @@ SYMBOLS = {
 	'nwayhip_zones_args_bytes': (ctypes.c_size_t, [_vp]),
 	'nwayhip_zones_enqueue': (ctypes.c_int, [_vp, ctypes.POINTER(ZoneRun), _vp, ctypes.c_size_t, _vp]),
 	'nwayhip_zones_batched': (ctypes.c_int32, [_vp]),
+	'nwayhip_zones_set_registration': (ctypes.c_int, [_vp, _i32]),
 	'nwayhip_split_buffer_bytes': (ctypes.c_size_t, [_vp, _i32, _i64]),
 	'nwayhip_split_front_enqueue': (ctypes.c_int, [_vp, ctypes.POINTER(Catalogue), _vp, ctypes.c_size_t, ctypes.POINTER(Split), _vp, _vp]),
 	'nwayhip_split_back_enqueue': (ctypes.c_int, [_vp, ctypes.POINTER(Catalogue), _vp, ctypes.c_size_t, ctypes.POINTER(Split), ctypes.POINTER(Table), _vp, _vp]),
@@ -708,7 +709,12 @@ class ZoneBatch(object):
 	keeps its workspace, table and status block; ``enqueue`` takes the zones' catalogue lists in the plans' order.  Where
 	the plans do not qualify (see the header) the zones go out one after the other: ``batched`` says which it was."""
 
-	def __init__(self, plans):
+	REGISTRATION = dict(auto=0, atomics=1, owner=2)  # NWAYHIP_ZONES_REG_*
+
+	def __init__(self, plans, registration='auto'):
+		"""registration: how the set registers its primaries -- 'atomics' (every claim an atomic in memory, as a plan of its own),
+		'owner' (owner-computes: records, buckets, one workgroup per slice of a table claiming in LDS; csrc/zones.inc), 'auto'
+		(owner from 200 000 primaries per set on).  Same tables' invariants, same results."""
 		self.lib = load()
 		self.plans = list(plans)
 		if not 1 <= len(self.plans) <= MAXZONES:
@@ -718,6 +724,7 @@ class ZoneBatch(object):
 		h = ctypes.c_void_p()
 		check(self.lib.nwayhip_zones_create(ctypes.byref(h), handles, len(self.plans)))
 		self.handle = h
+		check(self.lib.nwayhip_zones_set_registration(self.handle, self.REGISTRATION[registration]))
 		t = torch()
 		self.args_bytes = int(self.lib.nwayhip_zones_args_bytes(self.handle))
 		self.args = t.empty(self.args_bytes + 256, dtype=t.uint8, device=self.device)
@@ -742,6 +749,11 @@ class ZoneBatch(object):
 	def batched(self):
 		"""whether the last enqueue went out as one launch set"""
 		return bool(self.lib.nwayhip_zones_batched(self.handle))
+
+	@property
+	def owner_computes(self):
+		"""whether the last enqueue's registration was owner-computes"""
+		return int(self.lib.nwayhip_zones_batched(self.handle)) == 2
 
 	def close(self):
 		if getattr(self, 'handle', None):

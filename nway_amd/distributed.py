@@ -851,7 +851,7 @@ class ZoneShardedMatch(MagnitudePriors):
 	ZONE_BINS = 1 << 16
 
 	def __init__(self, primary, secondaries, match_radius, prior_completeness, device, group=None,
-			prob_ratio_secondary=0.5, tuning=None, comm=None, zones_per_rank=1, streams=1, local_only=False, one_launch=True):
+			prob_ratio_secondary=0.5, tuning=None, comm=None, zones_per_rank=1, streams=1, local_only=False, one_launch=True, registration='auto'):
 		"""local_only: this process alone, whatever process group is up (the catalogues handed in are the WHOLE catalogues; no collective
 		is issued) -- ``bench.py`` measures the one-GPU reference of a job on rank 0 that way while the other ranks wait.
 		zones_per_rank: every rank holds this many declination zones and runs them one after the other in a step (round 5).
@@ -883,8 +883,10 @@ class ZoneShardedMatch(MagnitudePriors):
 		self.zones_per_rank = max(1, int(zones_per_rank))
 		self.nstreams = max(1, int(streams))
 		self.one_launch = bool(one_launch)
+		self.registration = registration   # of a launch set: 'auto' | 'atomics' | 'owner' (_hip.ZoneBatch)
 		self._batch = None
 		self.batched = False
+		self.owner_computes = False
 		self.plan = None
 		self.setup_seconds = None
 		self.setup()
@@ -1085,7 +1087,8 @@ class ZoneShardedMatch(MagnitudePriors):
 			ngroups = min(self.nstreams, len(live) // 2) if self.nstreams > 1 else 1
 			if self._batch is None:
 				bounds = [len(live) * g // max(ngroups, 1) for g in range(max(ngroups, 1) + 1)]
-				self._batch = [(_hip.ZoneBatch([z['plan'] for z in live[lo:hi]]), [z['cats'] for z in live[lo:hi]]) for lo, hi in zip(bounds[:-1], bounds[1:])]
+				self._batch = [(_hip.ZoneBatch([z['plan'] for z in live[lo:hi]], registration=self.registration), [z['cats'] for z in live[lo:hi]])
+					for lo, hi in zip(bounds[:-1], bounds[1:])]
 			if len(self._batch) == 1:
 				self._batch[0][0].enqueue(self._batch[0][1])
 			else:
@@ -1099,6 +1102,7 @@ class ZoneShardedMatch(MagnitudePriors):
 				for st in self._streams:
 					cur.wait_stream(st)
 			self.batched = all(b.batched for b, _ in self._batch)
+			self.owner_computes = all(b.owner_computes for b, _ in self._batch)
 			return
 		if len(live) <= 1 or self.nstreams == 1:
 			for z in live:

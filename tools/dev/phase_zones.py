@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 dev = torch.device('cuda', 0)
 BLOCKS, STAMPS = 1024, 8
-buf = torch.zeros(3 * BLOCKS * STAMPS, dtype=torch.int64, device=dev)
+buf = torch.zeros(4 * BLOCKS * STAMPS, dtype=torch.int64, device=dev)
 os.environ["NWAYHIP_DEV"] = "1"
 os.environ["NWAYHIP_DBG_PTR"] = str(buf.data_ptr())
 os.environ.setdefault("NWAYHIP_LIBRARY", os.path.join(ROOT, "tools", "dev", "bin", "lib_dev.so"))
@@ -29,15 +29,16 @@ for _ in range(5):
 	eng.step()
 torch.cuda.synchronize()
 assert eng.batched
-names = {0: ('k_register_x_zones', ['start', None, 'claims + stores landed', 'end']),
+names = {0: (('k_register_pre_zones', ['start', 'ra / dec landed', 'trig done, barrier', 'records staged', 'records written', 'end']) if os.environ.get('PHASE_OWNER', '1') == '1' else ('k_register_x_zones', ['start', None, 'claims + stores landed', 'end'])),
 	1: ('k_sweep_zones', ['start', 'bitmap in LDS', 'wave 0 done streaming', 'all waves done', 'probes landed', 'end']),
+	3: ('k_claim_zones', ['start', 'run lengths scanned, slice set up', 'records claimed (this thread)', 'all claimed', 'slice written back']),
 	2: ('k_tail2_zones', ['start', 'cnt/slot/sigma landed', 'block scan', 'lookback', 'rows landed', 'group stats landed', 'items set up', 'separations done'])}
 acc = {}
 for rep in range(6):
 	buf.zero_()
 	eng.step()
 	torch.cuda.synchronize()
-	t = buf.cpu().numpy().reshape(3, BLOCKS, STAMPS)
+	t = buf.cpu().numpy().reshape(4, BLOCKS, STAMPS)
 	for k, (kname, labels) in names.items():
 		used = t[k][:, 0] > 0
 		tk = t[k][used][:, :len(labels)].astype(np.float64) * 0.01
@@ -49,7 +50,7 @@ for k, (kname, labels) in names.items():
 	for i, lab in enumerate(labels):
 		if lab is not None:
 			print('    %-26s %7.2f | %7.2f | %7.2f' % (lab, rel[:, :, i].mean(), np.percentile(rel[:, :, i], 90, axis=1).mean(), rel[:, :, i].max(axis=1).mean()))
-t = buf.cpu().numpy().reshape(3, BLOCKS, STAMPS).astype(np.float64) * 0.01
+t = buf.cpu().numpy().reshape(4, BLOCKS, STAMPS).astype(np.float64) * 0.01
 f = lambda k, i, red: red(t[k][t[k][:, 0] > 0][:, i])
 print('last run: register start -> sweep start %.2f, sweep start -> tail start %.2f, tail start -> last stamped tail workgroup end %.2f us' % (
 	f(1, 0, np.min) - f(0, 0, np.min), f(2, 0, np.min) - f(1, 0, np.min), f(2, 5, np.max) - f(2, 0, np.min)))
