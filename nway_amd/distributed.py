@@ -1049,10 +1049,10 @@ class ZoneShardedMatch(MagnitudePriors):
 		for z in self.zones:
 			self._build_zone(z)
 		self._streams = None
-		if self._batch is not None:
+		if getattr(self, '_batch', None) is not None:
 			for b, _ in self._batch:
 				b.close()
-			self._batch = None
+		self._batch = None
 		z0 = self.zones[0]
 		self.plan, self.cats, self.empty, self.status = z0['plan'], z0['cats'], all(z['empty'] for z in self.zones), z0['status']
 

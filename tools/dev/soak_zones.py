@@ -41,6 +41,7 @@ class OneZone(distributed.ZoneShardedMatch):
 		self.primary_sizes = [len(whole[0]['ra'])]
 		self.sec_global = [len(t['ra']) for t in whole[1:]]
 		self.zones_per_rank, self.nstreams = 1, 1
+		self.one_launch, self.registration, self._batch, self.batched, self.owner_computes = True, 'auto', None, False, False
 		self.zones = [dict(primary=zone_tables[0], primary_gidx=gidx[0], secondaries=zone_tables[1:], sec_gidx=gidx[1:], plan=None, cats=None, empty=True, status=None)]
 		self._decide()
 		self.scheme = scheme  # (of the whole job)
@@ -73,14 +74,19 @@ for seed in range(lo, hi):
 		if len(sys.argv) > 3 and sys.argv[3] == 'local':
 			# round 5: ONE rank, several zones, cut and run by the engine itself (zones_per_rank, streams)
 			zpr, streams = int(rng.choice([2, 3, 5, 8])), int(rng.choice([1, 2, 3]))
-			eng = distributed.ZoneShardedMatch(tabs[0], tabs[1:], radius, comp, dev, zones_per_rank=zpr, streams=streams, local_only=True)
+			# (round 6: the zones of a step as launch sets where they qualify; their registration by atomics or owner-computes)
+			reg = str(rng.choice(['atomics', 'owner']))
+			eng = distributed.ZoneShardedMatch(tabs[0], tabs[1:], radius, comp, dev, zones_per_rank=zpr, streams=streams, local_only=True, registration=reg)
 			for _ in range(2):
 				eng.step()
 			got = eng.gather_table()
 			eng.close()
 			for key in want:
-				np.testing.assert_array_equal(got[key], want[key], err_msg='%s (zones %d, streams %d)' % (key, zpr, streams))
+				np.testing.assert_array_equal(got[key], want[key], err_msg='%s (zones %d, streams %d, %s, batched %s)' % (key, zpr, streams, reg, eng.batched))
 			rows += len(want[tabs[0]['name']])
+			sets = globals().setdefault('sets', [0, 0])
+			sets[0] += int(eng.batched)
+			sets[1] += int(getattr(eng, 'owner_computes', False))
 			continue
 		world = int(rng.choice([2, 3, 5]))
 		big = 1 + int(np.argmax([len(t['ra']) for t in tabs[1:]]))
@@ -118,4 +124,4 @@ for seed in range(lo, hi):
 	except Exception as e:
 		bad.append(seed)
 		print('seed %d (k %d, %s, world %s) FAILED: %s' % (seed, len(tabs), 'flat' if seed % 2 == 0 else 'sphere', locals().get('world'), str(e).strip().splitlines()[0][:200]))
-print('zone soak seeds %d..%d: %d rows compared bit for bit, %d failures %s, %.0f s' % (lo, hi - 1, rows, len(bad), bad, time.time() - t0))
+print('zone soak seeds %d..%d: %d rows compared bit for bit, %d failures %s, %.0f s; launch sets / owner-computes among them: %s' % (lo, hi - 1, rows, len(bad), bad, time.time() - t0, globals().get('sets')))
