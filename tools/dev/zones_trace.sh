@@ -16,12 +16,15 @@ for _ in range(5):
 	eng.step()
 torch.cuda.synchronize(dev)
 t0 = time.perf_counter()
+probe = torch.zeros(64, device=dev) if len(sys.argv) > 3 and sys.argv[3] == 'probe' else None
 for _ in range(20):
 	eng.step()
+	if probe is not None:
+		probe.add_(1.0)   # (a 64-element kernel right behind the tail: its "duration" in the trace = what the tail leaves behind)
 torch.cuda.synchronize(dev)
 print('us per pass', (time.perf_counter() - t0) * 1e6 / 20, 'batched', eng.batched)
 PY
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python /tmp/zones_job.py ${2:-8} ${3:-0} > $OUT/job.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python /tmp/zones_job.py ${2:-8} ${3:-0} ${4:-} > $OUT/job.log 2>&1
 tail -2 $OUT/job.log
 python - <<PY
 import csv, glob
