@@ -967,6 +967,41 @@ def main():
 				extra.close()
 			if first is not plan:
 				first.close()
+		if engine is None and len(plans) == 1 and args.two_pipelines and args.cpu_sample != 0:
+			# supplementary, never `value`: the SAME catalogues cut into four declination zones at set-up (the bucketing of the
+			# catalogues by zone is outside the pass, as an upload is) and the zones of a pass as ONE launch set -- one registration,
+			# one sweep, one tail launch (nwayhip_zones_enqueue): smaller cell tables (a quarter of the bitmap to copy into every sweep
+			# workgroup's LDS), every zone's workgroups on the XCDs whose L2 holds its tags
+			try:
+				from nway_amd import distributed as _dz
+				zeng = _dz.ZoneShardedMatch(primary, [secondary], args.radius, args.completeness, device, zones_per_rank=4, local_only=True)
+				try:
+					for _ in range(args.warmup + 10):
+						zeng.step()
+					torch.cuda.synchronize(device)
+					t1 = time.perf_counter()
+					for _ in range(args.steps):
+						zeng.step()
+					torch.cuda.synchronize(device)
+					msz = (time.perf_counter() - t1) * 1e3 / args.steps
+					stz = zeng.read_status()
+					# (the like-for-like one-zone time: the headline's plan on ONE secondary buffer too -- 160 MB that the Infinity Cache holds)
+					for _ in range(args.warmup):
+						plan.enqueue(cats)
+					torch.cuda.synchronize(device)
+					t1 = time.perf_counter()
+					for _ in range(args.steps):
+						plan.enqueue(cats)
+					torch.cuda.synchronize(device)
+					ms1 = (time.perf_counter() - t1) * 1e3 / args.steps
+					out['zones_one_launch_set'] = dict(zones=4, one_zone_same_buffer_ms=ms1, one_launch_set=bool(zeng.batched), ms_per_step=msz, rows=int(stz[_hip.ST_ROWS]), flags=int(stz[_hip.ST_FLAGS]),
+						value=int(stz[_hip.ST_ROWS]) / (msz * 1e-3), pass_frac=p_bytes / (msz * 1e-3) / 1e9 / HBM_PEAK_GBS, setup_s=zeng.setup_seconds,
+						note='supplementary: the headline\'s catalogues as four declination zones (cut once at set-up, ONE secondary buffer) in one launch set per pass; `value` above is the job as one zone')
+					assert out['zones_one_launch_set']['rows'] == rows_per_step and out['zones_one_launch_set']['flags'] == 0
+				finally:
+					zeng.close()
+			except Exception as e:
+				out['zones_one_launch_set'] = dict(error='%s: %s' % (type(e).__name__, e))
 		if args.profile_stages:
 			out['stages_ms'] = dict((name, ms[i] / max(launches[i], 1) * (launches[i] / float(args.steps)))
 				for i, name in enumerate(_hip.STAGE_NAMES))
