@@ -508,6 +508,20 @@ def test_zones_holding_one_source_or_none():
 		assert len(got['ncat']) == len(want) > 40
 		for key in want.columns:
 			np.testing.assert_array_equal(got[key], want[key].values, err_msg=key)
+	# the same two-way (round 6: such zones go out as ONE launch set -- zones without a secondary, with one, tables of 2^10 positions in
+	# one slice of the owner-computes registration)
+	want2 = nw.nway_match([a, b], 10., 0.9, logger=nw.NullOutputLogger())
+	for zpr, registration in ((16, 'atomics'), (16, 'owner'), (5, 'owner')):
+		eng = distributed.ZoneShardedMatch(a, [b], 10., 0.9, dev, zones_per_rank=zpr, local_only=True, registration=registration)
+		assert len(eng.zones) == zpr and min(len(z['secondaries'][0]['ra']) for z in eng.zones) <= 3  # (13 secondaries, 40 primaries: zones of a few sources)
+		for _ in range(3):
+			eng.step()
+		assert eng.batched and eng.owner_computes == (registration == 'owner')
+		got = eng.gather_table()
+		eng.close()
+		assert len(got['ncat']) == len(want2) > 40
+		for key in want2.columns:
+			np.testing.assert_array_equal(got[key], want2[key].values, err_msg=key)
 
 
 @pytest.mark.parametrize('flat,zpr,registration', [(False, 4, 'atomics'), (True, 3, 'atomics'), (False, 8, 'owner'), (True, 3, 'owner'), (False, 5, 'owner')])
