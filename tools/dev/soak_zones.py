@@ -123,5 +123,5 @@ for seed in range(lo, hi):
 		rows += len(want[pname])
 	except Exception as e:
 		bad.append(seed)
-		print('seed %d (k %d, %s, world %s) FAILED: %s' % (seed, len(tabs), 'flat' if seed % 2 == 0 else 'sphere', locals().get('world'), str(e).strip().splitlines()[0][:200]))
+		print('seed %d (k %d, %s, world %s) FAILED: %s' % (seed, len(tabs), 'flat' if seed % 2 == 0 else 'sphere', locals().get('world'), ' | '.join(str(e).strip().splitlines()[:8])[:600]))
 print('zone soak seeds %d..%d: %d rows compared bit for bit, %d failures %s, %.0f s; launch sets / owner-computes among them: %s' % (lo, hi - 1, rows, len(bad), bad, time.time() - t0, globals().get('sets')))
