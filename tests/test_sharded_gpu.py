@@ -469,7 +469,7 @@ def local_zone_worker(rank, world, port, outfile, k, flat, zpr, streams):
 		dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('world,k,flat,zpr,streams', [(1, 2, False, 4, 1), (1, 2, False, 4, 2), (1, 3, True, 3, 3), (2, 3, False, 2, 2)])
+@pytest.mark.parametrize('world,k,flat,zpr,streams', [(1, 2, False, 4, 1), (1, 2, False, 4, 2), (1, 3, True, 3, 3), (2, 3, False, 2, 2), (2, 2, False, 4, 1), (2, 2, True, 3, 1)])
 def test_several_zones_per_rank_on_device(tmp_path, world, k, flat, zpr, streams):
 	"""several declination zones per rank (ZoneShardedMatch(zones_per_rank=, streams=), round 5): a rank runs its zones one after the other, or
 	round robin on several HIP streams -- down to ONE rank whose zones keep each cell table inside the LDS: the table equals the
