@@ -863,3 +863,27 @@ def test_host_path_one_transfer_and_plan_cache(nw, monkeypatch):
 	assert again.plan.attempts == 1 and again.nrows == 37706
 	again.plan.release()
 	_hip.plan_cache_clear()
+
+
+def test_a_call_works_on_the_device_of_its_stream(nw):
+	"""include/nwayhip.h: `stream` -- csrc/common.inc: StreamDevice.  Null stream, the current stream, a stream of its own: the same
+	table, and the caller's current device is what it was.  With a second GPU (self-arming: skipped on a one-GPU box) the same job on
+	cuda:1 while cuda:0 stays current -- the launches go to the device of the stream, whatever is current."""
+	import torch
+	X, R, O = ell_tables()
+	tables = [X, O]
+	before = torch.cuda.current_device()
+	ref = run(nw, tables, 10., 0.9)
+	side = torch.cuda.Stream(device=torch.device('cuda', before))
+	with torch.cuda.stream(side):
+		other = run(nw, tables, 10., 0.9)
+	side.synchronize()
+	assert torch.cuda.current_device() == before
+	for c in ref:
+		np.testing.assert_array_equal(ref[c], other[c], err_msg=c)
+	if torch.cuda.device_count() < 2:
+		return
+	second = run(nw, tables, 10., 0.9, device='cuda:%d' % ((before + 1) % torch.cuda.device_count()))
+	assert torch.cuda.current_device() == before
+	for c in ref:
+		np.testing.assert_array_equal(ref[c], second[c], err_msg=c)
