@@ -849,6 +849,7 @@ class ZoneShardedMatch(MagnitudePriors):
 	"""
 
 	ZONE_BINS = 1 << 16
+	CUT_WHERE_RESIDENT = True   # (tests: False = the host-side cut also where this process is alone)
 
 	def __init__(self, primary, secondaries, match_radius, prior_completeness, device, group=None,
 			prob_ratio_secondary=0.5, tuning=None, comm=None, zones_per_rank=1, streams=1, local_only=False, one_launch=True, registration='auto'):
@@ -910,19 +911,30 @@ class ZoneShardedMatch(MagnitudePriors):
 		_dist().all_gather(sizes, t, group=self.group)
 		return [int(s.item()) for s in sizes]
 
-	def _zone_edges(self):
-		"""interior edges (world x zones_per_rank - 1 of them, ascending) of the declination zones: equal shares of the largest secondary catalogue"""
+	def _zone_edges(self, resident=None):
+		"""interior edges (world x zones_per_rank - 1 of them, ascending) of the declination zones: equal shares of the largest secondary catalogue.
+		resident: this process alone -- the catalogues' columns as ``setup`` has uploaded them; the histogram is then taken where they lie
+		(the same arithmetic, hence the same edges: a hundred million declinations are seconds of numpy on the host)"""
 		import torch
 		dist = _dist()
 		dev = self._exchange_device()
 		big = int(numpy.argmax(self.sec_global)) if self.sec_global else 0
+		nz = self.world * self.zones_per_rank
+		if resident is not None and self.secondary_slices:
+			d = resident[1 + big][1]
+			d = d[torch.isfinite(d)]
+			lo, hi = (float(d.min().item()), float(d.max().item())) if d.numel() else (numpy.inf, -numpy.inf)
+			if not (hi > lo):
+				return numpy.full(nz - 1, lo if numpy.isfinite(lo) else 0.0)
+			width = (hi - lo) / self.ZONE_BINS
+			h = torch.bincount(torch.clamp(((d - lo) / width).to(torch.int64), max=self.ZONE_BINS - 1), minlength=self.ZONE_BINS)
+			return self._edges_from_histogram(h.cpu().numpy(), lo, width, nz)
 		dec = numpy.asarray(self.secondary_slices[big]['dec'], dtype=float) if self.secondary_slices else numpy.zeros(0)
 		dec = dec[numpy.isfinite(dec)]
 		lim = torch.tensor([dec.min() if len(dec) else numpy.inf, -(dec.max() if len(dec) else -numpy.inf)], dtype=torch.float64, device=dev)
 		if self.world > 1:
 			dist.all_reduce(lim, op=dist.ReduceOp.MIN, group=self.group)
 		lo, hi = float(lim[0].item()), -float(lim[1].item())
-		nz = self.world * self.zones_per_rank
 		if not (hi > lo):
 			return numpy.full(nz - 1, lo if numpy.isfinite(lo) else 0.0)
 		width = (hi - lo) / self.ZONE_BINS
@@ -930,7 +942,11 @@ class ZoneShardedMatch(MagnitudePriors):
 		h = torch.as_tensor(hist).to(dev)
 		if self.world > 1:
 			dist.all_reduce(h, group=self.group)
-		cum = numpy.cumsum(h.cpu().numpy())
+		return self._edges_from_histogram(h.cpu().numpy(), lo, width, nz)
+
+	@staticmethod
+	def _edges_from_histogram(hist, lo, width, nz):
+		cum = numpy.cumsum(hist)
 		total = int(cum[-1])
 		edges = []
 		for z in range(1, nz):
@@ -954,12 +970,42 @@ class ZoneShardedMatch(MagnitudePriors):
 		for n in [sum(self.primary_sizes)] + self.sec_global:
 			if n > _hip.CAPACITY_LIMIT:
 				raise _hip.NwayHipError('a catalogue of %d rows exceeds the int32 index range of the match table' % n)
-		self.edges = self._zone_edges()
+		# This process alone (one GPU, or ``local_only``): nothing travels between ranks, so the catalogues go up ONCE, as they are, and
+		# are cut into zones where they lie -- the host-side cut below (masks, gathers and a packed copy of a hundred million rows, then a
+		# pageable upload) was 6 of the 6.7 s of set-up of BASELINE configs[4] on one GPU.  Same rows in the same order either way.
+		resident = None
+		if world == 1 and self.CUT_WHERE_RESIDENT:
+			resident = []
+			for t in [self.primary] + list(self.secondary_slices):
+				cols = [t['ra'], t['dec']] + ([] if numpy.ndim(t['error']) == 0 else [t['error']])
+				resident.append(_hip.upload_columns(cols, dev) if torch.device(dev).type == 'cuda' else [_hip.to_device(c, dev) for c in cols])  # (the CPU tests' engines)
+		self.edges = self._zone_edges(resident)
 		margin = self.match_radius / 3600. * (1 + 1e-9) + 1e-12
 		self.moved_bytes = 0
 
 		zpr = self.zones_per_rank
 		nz = world * zpr
+
+		def cut_resident(table, cols, offset, seams):
+			"""``redistribute`` for this process alone: the zones of ``table`` out of its resident columns ``cols``"""
+			scalar_error = numpy.ndim(table['error']) == 0
+			ra, dec = cols[0], cols[1]
+			edges = torch.as_tensor(self.edges, dtype=torch.float64, device=dec.device)
+			m = margin if seams else 0.0
+			# (numpy.searchsorted(edges, x, side='right') of the host-side cut)
+			z_lo = torch.bucketize(dec - m, edges, right=True)
+			z_hi = torch.bucketize(dec + m, edges, right=True)
+			bad = ~torch.isfinite(dec)
+			z_lo[bad] = nz - 1
+			z_hi[bad] = nz - 1
+			out = []
+			for zl in range(zpr):
+				rows = torch.nonzero((z_lo <= zl) & (zl <= z_hi)).reshape(-1)  # (ascending: local order = global order)
+				t = dict(name=table['name'], ra=ra.index_select(0, rows), dec=dec.index_select(0, rows), area=table['area'],
+					error=(float(table['error']) if scalar_error else cols[2].index_select(0, rows)), mags=[], maghists=[], magnames=[])
+				self.moved_bytes += int(rows.numel()) * 8 * (len(cols) + 1 + (1 if zpr > 1 else 0))  # (what the packed rows of the exchange would hold)
+				out.append((t, (rows + offset).cpu().numpy().astype(numpy.int64)))
+			return out
 
 		def redistribute(table, offset, seams):
 			"""rows of ``table`` -> the ranks of their zones; returns per LOCAL zone (host-side bookkeeping aside, the columns stay where
@@ -1003,8 +1049,13 @@ class ZoneShardedMatch(MagnitudePriors):
 					error=(float(table['error']) if scalar_error else column(2)), mags=[], maghists=[], magnames=[])
 				out.append((t, part[:, g_col].cpu().numpy().astype(numpy.int64)))
 			return out
-		prim = redistribute(self.primary, self.primary_offset, False)
-		secs = [redistribute(sl, off, True) for sl, off in zip(self.secondary_slices, self.sec_offset)]
+		if resident is not None:
+			prim = cut_resident(self.primary, resident[0], self.primary_offset, False)
+			secs = [cut_resident(sl, cols, off, True) for sl, cols, off in zip(self.secondary_slices, resident[1:], self.sec_offset)]
+			del resident
+		else:
+			prim = redistribute(self.primary, self.primary_offset, False)
+			secs = [redistribute(sl, off, True) for sl, off in zip(self.secondary_slices, self.sec_offset)]
 		self.zones = []
 		for zl in range(zpr):
 			self.zones.append(dict(primary=prim[zl][0], primary_gidx=prim[zl][1], secondaries=[sc[zl][0] for sc in secs], sec_gidx=[sc[zl][1] for sc in secs],

@@ -200,6 +200,38 @@ def test_zone_sharded_equals_unsharded(tmp_path, world, k, zpr):
 		np.testing.assert_array_equal(got[key], want[key], err_msg=key)
 
 
+@pytest.mark.parametrize('scalar_error', [False, True])
+def test_zones_cut_where_resident_equal_the_host_side_cut(scalar_error):
+	"""a process alone cuts its zones out of the uploaded columns (torch.bucketize / nonzero where they lie, the histogram of the
+	edges likewise); with ranks to exchange with it cuts on the host and packs rows for the all-to-all-v.  Same edges, same rows
+	in the same order, same values -- also with NaN and infinite declinations, a scalar error, five zones and three catalogues"""
+	from nway_amd import distributed
+	from cpu_engines import OracleZoneShardedMatch
+	A, B, C = zone_edge_catalogues('lopsided')
+	B['dec'][13] = np.inf
+	C['dec'][5] = -np.inf
+	if scalar_error:
+		B = dict(B, error=1.0)
+
+	class HostCut(OracleZoneShardedMatch):
+		CUT_WHERE_RESIDENT = False
+
+	made = [cls(A, [B, C], 20., 0.85, device=torch.device('cpu'), zones_per_rank=5, local_only=True) for cls in (OracleZoneShardedMatch, HostCut)]
+	here, host = made
+	np.testing.assert_array_equal(here.edges, host.edges)
+	assert len(here.zones) == len(host.zones) == 5 and here.moved_bytes == host.moved_bytes
+	for zh, zo in zip(here.zones, host.zones):
+		np.testing.assert_array_equal(zh['primary_gidx'], zo['primary_gidx'])
+		for th, to in [(zh['primary'], zo['primary'])] + list(zip(zh['secondaries'], zo['secondaries'])):
+			for col in ('ra', 'dec', 'error'):
+				np.testing.assert_array_equal(np.asarray(th[col]), np.asarray(to[col]), err_msg=col)
+		for gh, go in zip(zh['sec_gidx'], zo['sec_gidx']):
+			np.testing.assert_array_equal(gh, go)
+	for e in made:
+		e.step()
+	assert here.total_rows() == host.total_rows() > 300
+
+
 def zone_edge_worker(rank, world, port, outfile, case):
 	os.environ['MASTER_ADDR'] = '127.0.0.1'
 	os.environ['MASTER_PORT'] = str(port)
